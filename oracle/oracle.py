@@ -1,0 +1,226 @@
+"""
+oracle/oracle.py -- ctypes access to the parity oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; nothing under pyclaw_amd/ does.
+
+Two back ends with the same Python call surface:
+
+* ``COracle``   -- this repo's C restatement (oracle/classic_oracle.c -> liboracle.so)
+* ``RefEuler2D``-- the REFERENCE's own Fortran (src/fortran/2d/classic/{step2ds,step2,flux2}.f,
+  1d/classic/{limiter,philim}.f, development/rp_approaches/rp{n,t}2_euler_5wave_rec_loc.f)
+  compiled unchanged by oracle/Makefile with flang into oracle/_ref/.  f2py is not
+  used: every scalar goes by reference, INTEGER*4 arrays as int32, arrays F-ordered.
+
+Arrays follow the reference's f2py call surface (clawpack.py:538-552):
+qold/qnew/aux are Fortran-ordered float64 ``(meqn, mx+2mbc, my+2mbc)``.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+RP_ADVECTION_1D = 1
+RP_ACOUSTICS_1D = 2
+RP_ACOUSTICS_2D = 10
+RP_EULER5_2D = 11
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _f64(a):
+    a = np.asarray(a, dtype=np.float64)
+    return a if a.flags.f_contiguous else np.asfortranarray(a)
+
+
+class COracle:
+    """C restatement (port).  See classic_oracle.c for the reference file:line map."""
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle not built: run `make -C oracle` (or __graft_entry__.build())")
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.orc_step2ds.restype = C.c_int
+        L.orc_step2ds.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double,
+                                  C.c_double, _ip, _ip, _dp, C.c_int]
+        L.orc_step2.restype = C.c_int
+        L.orc_step2.argtypes = L.orc_step2ds.argtypes[:-1]
+        L.orc_step1.restype = C.c_int
+        L.orc_step1.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
+                                C.c_double, C.c_double, _ip, _ip, _dp]
+        L.orc_rpn2.restype = C.c_int
+        L.orc_rpn2.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
+                               _dp, _dp, _dp]
+        L.orc_rpt2.restype = C.c_int
+        L.orc_rpt2.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+        L.orc_limiter.restype = None
+        L.orc_limiter.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip]
+        L.orc_philim.restype = C.c_double
+        L.orc_philim.argtypes = [C.c_double, C.c_double, C.c_int]
+
+    # -- f2py-shaped entry points -------------------------------------------------
+    def step2ds(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim, ids,
+                fwave=False):
+        """classic2.step2ds(...) -> (qnew, cfl); qnew updated in place (may alias qold)."""
+        meqn = qnew.shape[0]
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        method = np.ascontiguousarray(method, dtype=np.int32)
+        mthlim = np.ascontiguousarray(mthlim, dtype=np.int32)
+        maux = int(method[6])
+        auxp = _d(aux) if (aux is not None and maux > 0) else _d(np.zeros(1))
+        cfl = C.c_double(0.0)
+        assert qnew.flags.f_contiguous and qold.flags.f_contiguous
+        rc = self.lib.orc_step2ds(rp, _d(par), int(fwave), maxm, meqn, len(mthlim), maux, mbc, mx, my,
+                                  _d(qold), _d(qnew), auxp, dx, dy, dt, _i(method), _i(mthlim),
+                                  C.byref(cfl), ids)
+        if rc:
+            raise RuntimeError("oracle: unknown Riemann solver id %d" % rp)
+        return qnew, cfl.value
+
+    def step2(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim,
+              fwave=False):
+        meqn = qnew.shape[0]
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        method = np.ascontiguousarray(method, dtype=np.int32)
+        mthlim = np.ascontiguousarray(mthlim, dtype=np.int32)
+        maux = int(method[6])
+        auxp = _d(aux) if (aux is not None and maux > 0) else _d(np.zeros(1))
+        cfl = C.c_double(0.0)
+        assert qnew.flags.f_contiguous and qold.flags.f_contiguous
+        rc = self.lib.orc_step2(rp, _d(par), int(fwave), maxm, meqn, len(mthlim), maux, mbc, mx, my,
+                                _d(qold), _d(qnew), auxp, dx, dy, dt, _i(method), _i(mthlim),
+                                C.byref(cfl))
+        if rc:
+            raise RuntimeError("oracle: unknown Riemann solver id %d" % rp)
+        return qnew, cfl.value
+
+    def step1(self, rp, par, mbc, mx, q, aux, dx, dt, method, mthlim):
+        meqn = q.shape[0]
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        method = np.ascontiguousarray(method, dtype=np.int32)
+        mthlim = np.ascontiguousarray(mthlim, dtype=np.int32)
+        maux = int(method[6])
+        auxp = _d(aux) if (aux is not None and maux > 0) else _d(np.zeros(1))
+        cfl = C.c_double(0.0)
+        assert q.flags.f_contiguous
+        rc = self.lib.orc_step1(rp, _d(par), meqn, len(mthlim), maux, mbc, mx, _d(q), auxp, dx, dt,
+                                _i(method), _i(mthlim), C.byref(cfl))
+        if rc:
+            raise RuntimeError("oracle: unknown Riemann solver id %d" % rp)
+        return q, cfl.value
+
+    # -- slice-level pieces -------------------------------------------------------
+    def rpn2(self, rp, par, ixy, mwaves, mbc, mx, q1d):
+        meqn = q1d.shape[0]
+        n = mx + 2 * mbc
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        wave = np.zeros((meqn, mwaves, n), order="F")
+        s = np.zeros((mwaves, n), order="F")
+        amdq = np.zeros((meqn, n), order="F")
+        apdq = np.zeros((meqn, n), order="F")
+        rc = self.lib.orc_rpn2(rp, _d(par), ixy, meqn, mwaves, mbc, mx, _d(_f64(q1d)), _d(wave), _d(s),
+                               _d(amdq), _d(apdq))
+        assert rc == 0
+        return wave, s, amdq, apdq
+
+    def rpt2(self, rp, par, ixy, mbc, mx, q1d, asdq):
+        meqn = q1d.shape[0]
+        n = mx + 2 * mbc
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        bm = np.zeros((meqn, n), order="F")
+        bp = np.zeros((meqn, n), order="F")
+        rc = self.lib.orc_rpt2(rp, _d(par), ixy, meqn, mbc, mx, _d(_f64(q1d)), _d(_f64(asdq)), _d(bm),
+                               _d(bp))
+        assert rc == 0
+        return bm, bp
+
+    def limiter(self, mbc, mx, wave, s, mthlim):
+        meqn, mwaves, _ = wave.shape
+        mthlim = np.ascontiguousarray(mthlim, dtype=np.int32)
+        wave = np.array(wave, order="F", dtype=np.float64)
+        self.lib.orc_limiter(meqn, mwaves, mbc, mx, _d(wave), _d(_f64(s)), _i(mthlim))
+        return wave
+
+    def philim(self, a, b, meth):
+        return self.lib.orc_philim(a, b, meth)
+
+
+class RefEuler2D:
+    """The reference Fortran itself (flang build under oracle/_ref/), Euler 5-wave only.
+
+    Call order of the 28 by-reference arguments follows step2ds.f:2-5.
+    """
+
+    rp = RP_EULER5_2D
+
+    class _CParam(C.Structure):
+        _fields_ = [("gamma", C.c_double), ("gamma1", C.c_double)]
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "_ref", "libref_euler2d.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.cparam = self._CParam.in_dll(self.lib, "cparam_")
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "libref_euler2d.so"))
+
+    def _call(self, name, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim, ids):
+        self.cparam.gamma, self.cparam.gamma1 = float(par[0]), float(par[1])
+        meqn = qnew.shape[0]
+        method = np.ascontiguousarray(method, dtype=np.int32)
+        mthlim = np.ascontiguousarray(mthlim, dtype=np.int32)
+        mwaves = len(mthlim)
+        maux_decl = max(int(method[6]), 1)
+        n = maxm + 2 * mbc
+        qadd = np.zeros((meqn, n), order="F")
+        fadd = np.zeros((meqn, n), order="F")
+        gadd = np.zeros((meqn, 2, n), order="F")
+        q1d = np.zeros((meqn, n), order="F")
+        dtdx1d = np.zeros(n)
+        dtdy1d = np.zeros(n)
+        aux1 = np.zeros((maux_decl, n), order="F")
+        aux2 = np.zeros((maux_decl, n), order="F")
+        aux3 = np.zeros((maux_decl, n), order="F")
+        mwork = n * (5 * meqn + mwaves + meqn * mwaves)
+        work = np.zeros(mwork)
+        if aux is None:
+            aux = np.zeros((1,) + qnew.shape[1:], order="F")
+        ci = lambda v: C.byref(C.c_int(v))
+        cd = lambda v: C.byref(C.c_double(v))
+        cfl = C.c_double(0.0)
+        args = [ci(maxm), ci(meqn), ci(mwaves), ci(maux_decl), ci(mbc), ci(mx), ci(my),
+                _d(qold), _d(qnew), _d(aux), cd(dx), cd(dy), cd(dt), _i(method), _i(mthlim),
+                C.byref(cfl), _d(qadd), _d(fadd), _d(gadd), _d(q1d), _d(dtdx1d), _d(dtdy1d),
+                _d(aux1), _d(aux2), _d(aux3), _d(work), ci(mwork)]
+        if ids is not None:
+            args.append(ci(ids))
+        getattr(self.lib, name)(*args)
+        return qnew, cfl.value
+
+    def step2ds(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim, ids,
+                fwave=False):
+        assert rp == RP_EULER5_2D and not fwave
+        return self._call("step2ds_", par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method,
+                          mthlim, ids)
+
+    def step2(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim,
+              fwave=False):
+        assert rp == RP_EULER5_2D and not fwave
+        return self._call("step2_", par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method,
+                          mthlim, None)
