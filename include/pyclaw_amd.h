@@ -1,0 +1,187 @@
+/*
+ * pyclaw_amd.h -- C ABI of libpyclaw_amd.so (MI355X / gfx950 HIP implementation of
+ * PyClaw's classic + SharpClaw hot path).
+ *
+ * What this boundary replaces in the reference (paths relative to the reference tree):
+ * the f2py extension modules classic1/classic2/(classic3)/sharpclaw1/sharpclaw2 that
+ * src/pyclaw/clawpack.py:323,538-552 and src/pyclaw/sharpclaw.py:385,558 import and
+ * call, plus the ghost-cell/backup array traffic those Python drivers do around them
+ * (src/pyclaw/solver.py:315-452, :660, :690; src/petclaw/state.py:236-269 for the
+ * halo exchange and src/petclaw/cfl.py:29-31 for the CFL all-reduce).
+ *
+ * Two layers:
+ *   1. "f2py-shaped" stateless calls on HOST arrays (pcl_step1 / pcl_step2ds /
+ *      pcl_step2): same argument meaning as the Fortran subroutines, Fortran array
+ *      order, caller owns every array.  A maintainer can bind these in place of the
+ *      f2py modules without touching the Python drivers (PCIe traffic every call).
+ *   2. A resident solver handle (pcl_create ...): q/aux live in HBM across steps,
+ *      ghost cells, backup/restore, CFL reduction and halo exchange run on the device.
+ *      This is what the pyclaw_amd ClawSolver / SharpClawSolver classes use.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * PCL_E* code and leaves a message for pcl_last_error(); host arrays are Fortran
+ * ordered float64 with the component index fastest, q(m,i,j) at
+ * q[(m) + meqn*((i) + (mx+2*mbc)*(j))] (0-based, ghost cells included) exactly like the
+ * reference's qbc (doc/differences.rst:9-17).  One host thread per solver handle.
+ * There is NO CPU fallback: every entry point fails with PCL_ENODEVICE without a GPU.
+ */
+#ifndef PYCLAW_AMD_H
+#define PYCLAW_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCL_MAX_WAVES 8
+#define PCL_MAX_RP_PARAMS 8
+
+/* error codes */
+#define PCL_OK 0
+#define PCL_EINVAL (-1)    /* bad argument / unsupported configuration           */
+#define PCL_ENODEVICE (-2) /* no usable HIP device                               */
+#define PCL_EHIP (-3)      /* a HIP runtime call failed                          */
+#define PCL_ECOMM (-4)     /* RCCL failure                                       */
+#define PCL_ESTATE (-5)    /* call not valid in the handle's current state       */
+
+/* Riemann solver ids.  The reference selects the solver at link time (the rpn2/rpt2
+ * symbols of the app Makefile, e.g. apps/euler/2d/shockbubble/Makefile:3) and passes
+ * its scalars through `common /cparam/` (src/pyclaw/state.py:142-162); here it is an
+ * id plus the cparam values in declaration order. */
+#define PCL_RP_ADVECTION_1D 1 /* rp1_advection.f            cparam: u                   */
+#define PCL_RP_ACOUSTICS_1D 2 /* rp1_acoustics.f            cparam: rho,bulk,cc,zz      */
+#define PCL_RP_ACOUSTICS_2D 10 /* rpn2/rpt2_acoustics.f     cparam: rho,bulk,cc,zz      */
+#define PCL_RP_EULER5_2D 11    /* rpn2/rpt2_euler_5wave.f   cparam: gamma,gamma1        */
+
+/* boundary condition types = pyclaw.BC (src/pyclaw/solver.py:17-23) */
+#define PCL_BC_CUSTOM 0
+#define PCL_BC_OUTFLOW 1
+#define PCL_BC_PERIODIC 2
+#define PCL_BC_REFLECTING 3
+
+/* arithmetic mode */
+#define PCL_MATH_EXACT 0 /* no FMA contraction, IEEE divide/sqrt: bit-identical to the  */
+                         /* reference Fortran built without FMA (the parity mode)        */
+
+typedef struct pcl_solver pcl_solver;
+
+typedef struct pcl_config {
+    int ndim;                       /* 1 or 2                                              */
+    int n[3];                       /* interior cells of THIS process' block: mx,my,(mz)   */
+    int mbc;                        /* ghost width (classic: 2)                            */
+    int meqn, mwaves, maux;
+    int method[7];                  /* as ClawSolver.set_method (clawpack.py:192-212):     */
+                                    /* [1]=order, [2]=-1 dim-split | order_trans,          */
+                                    /* [5]=mcapa+1 (0 = no capa), [6]=maux                 */
+    int mthlim[PCL_MAX_WAVES];      /* limiter per wave family (philim.f ids 0..5)         */
+    int fwave;                      /* 1: f-wave form (flux2fw.f:151-152)                  */
+    int rp;                         /* PCL_RP_*                                            */
+    double rp_params[PCL_MAX_RP_PARAMS];
+    double d[3];                    /* dx,dy,(dz)                                          */
+    int device;                     /* HIP device ordinal                                  */
+    int math;                       /* PCL_MATH_*                                          */
+} pcl_config;
+
+/* ---- library ---------------------------------------------------------------------- */
+const char *pcl_last_error(void);
+int pcl_version(void);
+int pcl_device_count(void);                     /* never initialises a context          */
+
+/* ---- layer 1: f2py-shaped stateless calls on host arrays ---------------------------- */
+/* classic1.step1(mbc,mx,q,aux,dx,dt,method,mthlim) -> (q,cfl)   step1.f:4-5, clawpack.py:323.
+ * q(meqn,1-mbc:mx+mbc) is updated in place for cells 1..mx (the two ghost cells the
+ * Fortran also touches are left unchanged: no caller reads them, clawpack.py:406). */
+int pcl_step1(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx,
+              double *q, const double *aux, double dx, double dt, const int *method,
+              const int *mthlim, double *cfl);
+
+/* classic2.step2ds(maxm,mbc,mx,my,qold,qnew,aux,dx,dy,dt,method,mthlim,aux1,aux2,aux3,work,ids)
+ * -> (qnew,cfl)   step2ds.f:2-5, clawpack.py:538-544.  qold may alias qnew.  The work
+ * arrays of the Fortran signature have no meaning here and are not taken. */
+int pcl_step2ds(int rp, const double *rp_params, int fwave, int meqn, int mwaves, int maux,
+                int mbc, int mx, int my, const double *qold, double *qnew, const double *aux,
+                double dx, double dy, double dt, const int *method, const int *mthlim,
+                double *cfl, int ids);
+
+/* classic2.step2(...) -> (qnew,cfl)   step2.f:2-5, clawpack.py:550-552 (unsplit). */
+int pcl_step2(int rp, const double *rp_params, int fwave, int meqn, int mwaves, int maux,
+              int mbc, int mx, int my, const double *qold, double *qnew, const double *aux,
+              double dx, double dy, double dt, const int *method, const int *mthlim,
+              double *cfl);
+
+/* ---- layer 2: resident solver -------------------------------------------------------- */
+int pcl_create(const pcl_config *cfg, pcl_solver **out);
+void pcl_destroy(pcl_solver *s);
+
+/* Host <-> device copies of the whole block.  with_ghosts=0: host array is state.q,
+ * (meqn,mx[,my]) Fortran order (get_qbc_from_q / set_q_from_qbc, state.py:171-206);
+ * with_ghosts=1: host array is qbc, (meqn,mx+2mbc[,my+2mbc]). */
+int pcl_put_q(pcl_solver *s, const double *host, int with_ghosts);
+int pcl_get_q(pcl_solver *s, double *host, int with_ghosts);
+int pcl_put_aux(pcl_solver *s, const double *host_auxbc); /* always with ghosts (auxbc)   */
+
+/* Ghost fill of one side of one dimension on the device: solver.py:384-452.
+ * side 0 = lower, 1 = upper.  PCL_BC_CUSTOM is not accepted here: use the strip calls
+ * (arbitrary user numpy code) or pcl_bc_const (inflow of a constant state). */
+int pcl_bc(pcl_solver *s, int idim, int side, int bctype);
+int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state /* [meqn] */);
+/* Copy the `width` outermost layers (ghost cells first) of one side to/from a host
+ * array shaped like qbc with that dimension cut to `width`: for custom BCs written in
+ * Python that only touch the strip (user_bc_lower/upper, solver.py:404-405,439-440). */
+int pcl_get_strip(pcl_solver *s, int idim, int side, int width, double *host);
+int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *host);
+
+/* One homogeneous step of length dt on the resident state (ghost cells must be filled):
+ * dim-split  = step2ds(ids=1) then step2ds(ids=2)          clawpack.py:538-546
+ * unsplit    = step2                                       clawpack.py:550-552
+ * 1-D        = step1                                       clawpack.py:323
+ * *cfl receives the max Courant number (local to this process).  The pre-step state
+ * stays available until the next call: pcl_undo_step() makes it current again (the
+ * reference's q_backup / retake path, solver.py:660,690) without any copy. */
+int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl);
+int pcl_undo_step(pcl_solver *s);
+/* Single directional sweep (ids = 1 or 2), qold -> qnew like step2ds; used by layer 1. */
+int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl);
+
+/* Explicit device-side backup/restore (needed when user code modifies q before the
+ * hyperbolic step: Strang source splitting, start_step). */
+int pcl_backup(pcl_solver *s);
+int pcl_restore(pcl_solver *s);
+
+/* Built-in device source terms for the reference apps' step_src callbacks.
+ * id 1: Euler radial-symmetry source, 2-stage RK (test/euler/2d/shockbubble.py:59-94);
+ *       aux[0] = radial coordinate; params = {gamma1, ndim}. */
+#define PCL_SRC_EULER_RADIAL 1
+int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int nparams);
+
+int pcl_sync(pcl_solver *s);
+
+/* Timing hooks for bench.py: HIP events recorded on the solver's compute stream. */
+int pcl_timer_start(pcl_solver *s);
+int pcl_timer_stop(pcl_solver *s, float *ms);
+/* Cumulative device time (ms) and launch count of the sweep kernels since the last
+ * reset, from HIP events around every sweep launch (enable before use). */
+int pcl_kernel_timing(pcl_solver *s, int enable);
+int pcl_kernel_timing_read(pcl_solver *s, double *ms_total, long *launches);
+
+/* ---- multi-GPU: one block per process, RCCL over xGMI -------------------------------- */
+/* Replaces PETSc DMDA globalToLocal (src/petclaw/state.py:254-269) and Vec.max
+ * (src/petclaw/cfl.py:29-31).  uid is the 128-byte ncclUniqueId produced by
+ * pcl_comm_unique_id() on rank 0 and distributed by the caller (any side channel).
+ * neighbors[8]: rank of the W,E,S,N,SW,SE,NW,NE neighbour block or -1 (physical
+ * boundary without periodic wrap). */
+int pcl_comm_unique_id(char uid[128]);
+int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128],
+                  const int neighbors[8]);
+int pcl_halo_exchange(pcl_solver *s);          /* faces + corners, width mbc            */
+int pcl_halo_exchange_aux(pcl_solver *s);
+int pcl_allreduce_max(pcl_solver *s, double *value);
+
+/* ---- debug / self-test --------------------------------------------------------------- */
+/* Runs the wavefront neighbour-shift primitive on 64 values: left[l]=in[l-1],
+ * right[l]=in[l+1] (end lanes keep their own value). */
+int pcl_debug_wave_shift(const double *in64, double *left64, double *right64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYCLAW_AMD_H */

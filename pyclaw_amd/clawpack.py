@@ -1,0 +1,242 @@
+r"""
+Classic Clawpack solvers on MI355X (reference: src/pyclaw/clawpack.py).
+
+``ClawSolver1D`` / ``ClawSolver2D`` keep the reference's attributes and step structure
+(start_step, Strang/Godunov source splitting, step_hyperbolic, CFL check: clawpack.py:114-165);
+``step_hyperbolic`` calls the resident HIP path of libpyclaw_amd instead of the f2py modules
+``classic1.step1`` / ``classic2.step2ds`` / ``classic2.step2`` (clawpack.py:323,538-552).
+
+kernel_language: 'HIP' (default).  'Fortran' is accepted as an alias so reference scripts run
+unchanged; 'Python' (the reference's pure-numpy 1-D kernel) is not provided.
+"""
+import numpy as np
+
+from . import _lib, riemann
+from .solver import Solver, DeviceBC
+
+
+class DeviceSource(object):
+    """A source-term step (``solver.step_src``) that libpyclaw_amd applies on the device.
+
+    A plain Python ``step_src(solver,state,dt)`` still works, but forces a device->host->device
+    round trip of q per call (arbitrary numpy code cannot run on the GPU)."""
+
+    def apply(self, solver, state, dt):
+        raise NotImplementedError
+
+
+class EulerRadialSource(DeviceSource):
+    """Geometric source of the 2-D Euler equations with radial symmetry, 2-stage RK -- the
+    ``euler_rad_src`` / ``step_Euler_radial`` callback of the reference's shock-bubble scripts
+    (test/euler/2d/shockbubble.py:59-94).  aux[0] must hold the radial coordinate."""
+
+    def __init__(self, gamma1, ndim=2):
+        self.params = np.array([gamma1, float(ndim)], dtype=np.float64)
+
+    def apply(self, solver, state, dt):
+        _lib.check(_lib.lib().pcl_src(solver._h, 1, dt, _lib.d(self.params), 2))
+
+
+class ClawSolver(Solver):
+    r"""Generic classic Clawpack solver (clawpack.py:24-262)."""
+
+    def __init__(self, data=None):
+        for attr in ['limiters', 'order', 'src_split', 'fwave', 'step_src', 'start_step']:
+            if attr not in self._required_attrs:
+                self._required_attrs.append(attr)
+        self._default_attr_values['mbc'] = 2
+        self._default_attr_values['limiters'] = 1           # limiters.tvd.minmod
+        self._default_attr_values['order'] = 2
+        self._default_attr_values['src_split'] = 1
+        self._default_attr_values['fwave'] = False
+        self._default_attr_values['step_src'] = None
+        self._default_attr_values['start_step'] = None
+        self._default_attr_values['kernel_language'] = 'HIP'
+        self._default_attr_values['verbosity'] = 0
+        self._default_attr_values['cfl_max'] = 1.0
+        self._default_attr_values['cfl_desired'] = 0.9
+        self.rp = None
+        super(ClawSolver, self).__init__(data)
+
+    # ---------------------------------------------------------------- time stepping
+    def step(self, solution):
+        r"""clawpack.py:114-165"""
+        state = solution.states[0]
+        if self.start_step is not None:
+            self._pull(state)
+            self.start_step(self, solution)
+            self._push(state)
+
+        if self.src_split == 2 and self.step_src is not None:
+            self._apply_src(state, self.dt / 2.0)
+
+        self.step_hyperbolic(solution)
+
+        if self.cfl.get_cached_max() >= self.cfl_max:
+            return False
+
+        if self.step_src is not None:
+            if self.src_split == 2:
+                self._apply_src(state, self.dt / 2.0)
+            if self.src_split == 1:
+                self._apply_src(state, self.dt)
+        return True
+
+    def _apply_src(self, state, dt):
+        if isinstance(self.step_src, DeviceSource):
+            self.step_src.apply(self, state, dt)
+            self._host_stale = True
+        else:
+            self._pull(state)
+            self.step_src(self, state, dt)
+            self._push(state)
+
+    def _pre_step_modifies_q(self):
+        return self.start_step is not None or (self.src_split == 2 and self.step_src is not None)
+
+    def _backup(self, state):
+        # Only code that changes q BEFORE the hyperbolic step needs a real copy; otherwise the
+        # pre-step buffer survives the step and "restore" is a pointer swap.
+        self._copied_backup = self._pre_step_modifies_q()
+        if self._copied_backup:
+            _lib.check(_lib.lib().pcl_backup(self._h))
+
+    def _restore(self, state):
+        if self._copied_backup:
+            _lib.check(_lib.lib().pcl_restore(self._h))
+        else:
+            _lib.check(_lib.lib().pcl_undo_step(self._h))
+        self._host_stale = True
+
+    def check_cfl_settings(self):
+        pass
+
+    def step_hyperbolic(self, solution):
+        r"""One homogeneous step on the resident state (clawpack.py:299-323,510-555)."""
+        import ctypes
+        state = solution.states[0]
+        self.apply_q_bcs(state)
+        cfl = ctypes.c_double(0.0)
+        _lib.check(_lib.lib().pcl_step_hyperbolic(self._h, self.dt, ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+        self._host_stale = True
+        self.cfl.update_global_max(cfl.value)
+
+    def set_mthlim(self):
+        r"""clawpack.py:181-190"""
+        self.mthlim = self.limiters
+        if not isinstance(self.limiters, list):
+            self.mthlim = [self.mthlim]
+        if len(self.mthlim) == 1:
+            self.mthlim = self.mthlim * self.mwaves
+        if len(self.mthlim) != self.mwaves:
+            raise Exception('Length of solver.limiters is not equal to 1 or to solver.mwaves')
+
+    def set_method(self, state):
+        r"""clawpack.py:192-212"""
+        self.method = np.empty(7, dtype=np.int32, order='F')
+        self.method[0] = self.dt_variable
+        self.method[1] = self.order
+        if self.ndim == 1:
+            self.method[2] = 0
+        elif self.dim_split:
+            self.method[2] = -1
+        else:
+            self.method[2] = self.order_trans
+        self.method[3] = self.verbosity
+        self.method[4] = 0
+        self.method[5] = state.mcapa + 1
+        self.method[6] = state.maux
+
+    def _default_rp(self, state):
+        raise Exception("solver.rp is not set: choose a Riemann solver from pyclaw_amd.riemann "
+                        "(the reference links one per app Makefile)")
+
+    def setup(self, solution):
+        r"""clawpack.py:214-238: mbc, mthlim, method, cparam, BC arrays -- plus the device handle."""
+        if self.kernel_language not in ('HIP', 'Fortran'):
+            raise Exception("Unrecognized kernel_language; pyclaw_amd provides 'HIP' "
+                            "('Fortran' is accepted as an alias)")
+        state = solution.states[0]
+        state.set_mbc(self.mbc)
+        self.check_cfl_settings()
+        self.set_mthlim()
+        self.set_method(state)
+
+        rp = riemann.get(self.rp) if self.rp is not None else self._default_rp(state)
+        if rp.ndim != self.ndim:
+            raise Exception("Riemann solver %s is %d-D but the solver is %d-D" % (rp.name, rp.ndim, self.ndim))
+        if rp.mwaves != self.mwaves:
+            raise Exception("solver.mwaves=%d but Riemann solver %s has %d waves" % (self.mwaves, rp.name, rp.mwaves))
+        if rp.meqn != state.meqn:
+            raise Exception("state.meqn=%d but Riemann solver %s has %d equations" % (state.meqn, rp.name, rp.meqn))
+        params = rp.params(state.aux_global)          # the cparam common block (state.py:142-162)
+
+        self._release()
+        cfg = _lib.Config()
+        cfg.ndim = self.ndim
+        ng = state.grid.ng
+        for k in range(self.ndim):
+            cfg.n[k] = int(ng[k])
+            cfg.d[k] = float(state.grid.d[k])
+        cfg.mbc = self.mbc
+        cfg.meqn = state.meqn
+        cfg.mwaves = self.mwaves
+        cfg.maux = state.maux
+        for k in range(7):
+            cfg.method[k] = int(self.method[k])
+        for k, m in enumerate(self.mthlim):
+            cfg.mthlim[k] = int(m)
+        cfg.fwave = int(bool(self.fwave))
+        cfg.rp = rp.id
+        for k, v in enumerate(params):
+            cfg.rp_params[k] = v
+        from . import parallel
+        cfg.device = parallel.local_rank() if state.decomp is not None else int(getattr(self, 'device', 0))
+        cfg.math = 0
+        import ctypes
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().pcl_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+
+        self.allocate_bc_arrays(state)
+        self._setup_halo(state)
+        if self.auxbc is not None:
+            _lib.check(_lib.lib().pcl_put_aux(self._h, _lib.d(_lib.fortran64(self.auxbc))))
+            if self._halo_active:
+                _lib.check(_lib.lib().pcl_halo_exchange_aux(self._h))
+
+    def teardown(self):
+        super(ClawSolver, self).teardown()
+
+
+class ClawSolver1D(ClawSolver):
+    r"""Clawpack evolution routine in 1D (clawpack.py:268-406)."""
+
+    def __init__(self, data=None):
+        self.ndim = 1
+        super(ClawSolver1D, self).__init__(data)
+
+
+class ClawSolver2D(ClawSolver):
+    r"""2D classic solver (clawpack.py:412-558): dimensional splitting or unsplit with
+    transverse Riemann solves (``dim_split``, ``order_trans``)."""
+
+    no_trans = 0
+    trans_inc = 1
+    trans_cor = 2
+
+    def __init__(self, data=None):
+        self._default_attr_values['dim_split'] = True
+        self._default_attr_values['order_trans'] = self.trans_inc
+        self.ndim = 2
+        super(ClawSolver2D, self).__init__(data)
+
+    def check_cfl_settings(self):
+        if (not self.dim_split) and (self.order_trans == 0):
+            cfl_recommended = 0.5
+        else:
+            cfl_recommended = 1.0
+        if self.cfl_max > cfl_recommended:
+            import warnings
+            warnings.warn('cfl_max is set higher than the recommended value of %s' % cfl_recommended)
+            warnings.warn(str(self.cfl_desired))

@@ -1,0 +1,706 @@
+// pclaw.hip -- C ABI of libpyclaw_amd.so (see include/pyclaw_amd.h).
+// gfx950 only.  No CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pyclaw_amd.h"
+#include "classic.hpp"
+#include "halo.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(PCL_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+}  // namespace
+
+struct pcl_solver {
+    pcl_config cfg;
+    int I = 1, J = 1;     // cells incl. ghosts
+    long pitch = 0, plane = 0, total = 0;  // doubles
+    long aplane = 0;
+    double *q = nullptr, *t1 = nullptr, *t2 = nullptr, *bak = nullptr;
+    double *aux = nullptr;
+    double *stage = nullptr;  // AoS staging for host transfers (qbc-sized)
+    size_t stage_bytes = 0;
+    unsigned long long *cfl_dev = nullptr;
+    unsigned long long *cfl_host = nullptr;  // pinned
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double **undo_slot = nullptr;  // buffer that holds the pre-step state
+    bool timing = false;
+    struct Timed { hipEvent_t a, b; int which; };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> evpool;
+    double kt_ms[2] = {0, 0};
+    long kt_n[2] = {0, 0};
+    pcl::Halo halo;
+};
+
+namespace {
+
+using namespace pcl;
+
+// ---- layout conversion kernels: host Fortran AoS (m fastest) <-> device SoA planes ----
+// hostlike[(m) + meqn*(i + ni*j)] where (i,j) run over a window [io,io+ni) x [jo,jo+nj)
+__global__ void aos_to_soa(const double *__restrict__ src, double *__restrict__ dst, int nm, int ni,
+                           int nj, int io, int jo, long pitch, long plane) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= ni || j >= nj) return;
+    const long h = (long)nm * (i + (long)ni * j);
+    const long d = (long)(j + jo) * pitch + (i + io);
+    for (int m = 0; m < nm; m++) dst[m * plane + d] = src[h + m];
+}
+__global__ void soa_to_aos(const double *__restrict__ src, double *__restrict__ dst, int nm, int ni,
+                           int nj, int io, int jo, long pitch, long plane) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= ni || j >= nj) return;
+    const long h = (long)nm * (i + (long)ni * j);
+    const long d = (long)(j + jo) * pitch + (i + io);
+    for (int m = 0; m < nm; m++) dst[h + m] = src[m * plane + d];
+}
+
+// ---- ghost-cell fills, solver.py:384-452 ---------------------------------------------------
+// One thread per (transverse index t, ghost layer g, component m).
+__global__ void bc_kernel(double *q, int nm, int I, int J, long pitch, long plane, int mbc, int idim,
+                          int side, int type, const double *cstate) {
+    const int nt = idim == 0 ? J : I;
+    const int N = idim == 0 ? I : J;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)nt * mbc;
+    if (tid >= per * nm) return;
+    const int m = (int)(tid / per);
+    const int rem = (int)(tid % per);
+    const int g = rem / nt;  // ghost layer 0..mbc-1
+    const int t = rem % nt;
+    int dstk, srck;
+    double sign = 1.0;
+    if (side == 0) {
+        dstk = g;
+        if (type == PCL_BC_OUTFLOW) srck = mbc;
+        else if (type == PCL_BC_PERIODIC) srck = N - 2 * mbc + g;
+        else { srck = 2 * mbc - 1 - g; if (type == PCL_BC_REFLECTING && m == idim + 1) sign = -1.0; }
+    } else {
+        dstk = N - 1 - g;
+        if (type == PCL_BC_OUTFLOW) srck = N - mbc - 1;
+        else if (type == PCL_BC_PERIODIC) srck = 2 * mbc - 1 - g;  // q[N-mbc+k] = q[mbc+k], k=mbc-1-g
+        else { srck = N - 2 * mbc + g; if (type == PCL_BC_REFLECTING && m == idim + 1) sign = -1.0; }
+    }
+    const long d = idim == 0 ? (long)t * pitch + dstk : (long)dstk * pitch + t;
+    if (type == 100) {  // constant inflow state
+        q[m * plane + d] = cstate[m];
+        return;
+    }
+    const long s = idim == 0 ? (long)t * pitch + srck : (long)srck * pitch + t;
+    const double v = q[m * plane + s];
+    q[m * plane + d] = (sign < 0.0) ? -v : v;
+}
+
+// ---- Euler radial source, test/euler/2d/shockbubble.py:59-94 -------------------------------
+__global__ void src_euler_radial(double *q, const double *aux, int mbc, int mx, int my, long pitch,
+                                 long plane, double dt, double gamma1, double ndm1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= mx || j >= my) return;
+    const long g = (long)(j + mbc) * pitch + (i + mbc);
+    const double rad = aux[g];
+    const double q0 = q[g], q1 = q[plane + g], q2 = q[2 * plane + g], q3 = q[3 * plane + g];
+    const double dt2 = dt / 2.0;
+    double rho = q0;
+    double u = q1 / rho;
+    double v = q2 / rho;
+    double press = gamma1 * (q3 - 0.5 * rho * (u * u + v * v));
+    const double k2 = dt2 * ndm1 / rad;
+    const double s0 = q0 - k2 * q2;
+    const double s1 = q1 - k2 * rho * u * v;
+    const double s2 = q2 - k2 * rho * v * v;
+    const double s3 = q3 - k2 * v * (q3 + press);
+    rho = s0;
+    u = s1 / rho;
+    v = s2 / rho;
+    press = gamma1 * (s3 - 0.5 * rho * (u * u + v * v));
+    const double k1 = dt * ndm1 / rad;
+    q[g] = q0 - k1 * s2;
+    q[plane + g] = q1 - k1 * rho * u * v;
+    q[2 * plane + g] = q2 - k1 * rho * v * v;
+    q[3 * plane + g] = q3 - k1 * v * (s3 + press);
+}
+
+__global__ void shift_test_kernel(const double *in, double *l, double *r) {
+    const int t = threadIdx.x;
+    const double x = in[t];
+    l[t] = from_left(x);
+    r[t] = from_right(x);
+}
+
+// ---- sweep dispatch ---------------------------------------------------------------------------
+SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, double dt) {
+    SweepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.qin = qin;
+    a.qout = qout;
+    a.aux = s->aux;
+    a.pitch = s->pitch;
+    a.plane = s->plane;
+    a.I = s->I;
+    a.J = s->J;
+    a.mbc = s->cfg.mbc;
+    a.mx = s->cfg.n[0];
+    a.my = s->cfg.ndim > 1 ? s->cfg.n[1] : 1;
+    a.mcapa = s->cfg.method[5];
+    a.order = s->cfg.method[1];
+    for (int k = 0; k < PCL_MAX_WAVES; k++) a.mthlim[k] = s->cfg.mthlim[k];
+    a.dt = dt;
+    a.dx = s->cfg.d[ids - 1];
+    a.dtd = dt / s->cfg.d[ids - 1];
+    for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) a.par.v[k] = s->cfg.rp_params[k];
+    a.cfl = s->cfl_dev;
+    return a;
+}
+
+template <class RP, bool DIM1> int launch_x(pcl_solver *s, const SweepArgs &a) {
+    const int nstrips = (a.mx + STRIP - 1) / STRIP;
+    const long nwork = (long)nstrips * a.J;
+    const int wpb = 4;
+    const unsigned grid = (unsigned)((nwork + wpb - 1) / wpb);
+    const bool capa = a.mcapa > 0;
+    if (s->cfg.fwave) return fail(PCL_EINVAL, "fwave: no f-wave Riemann solver is built in yet");
+    if (capa)
+        hipLaunchKernelGGL((sweep_x_kernel<RP, true, false, DIM1>), dim3(grid), dim3(256), 0, s->stream,
+                           a, nstrips, nwork);
+    else
+        hipLaunchKernelGGL((sweep_x_kernel<RP, false, false, DIM1>), dim3(grid), dim3(256), 0,
+                           s->stream, a, nstrips, nwork);
+    HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+template <class RP> int launch_y(pcl_solver *s, const SweepArgs &a) {
+    const int ntiles_i = (a.I + YT_COLS - 1) / YT_COLS;
+    const int ntiles_j = (a.my + STRIP - 1) / STRIP;
+    const unsigned grid = (unsigned)ntiles_i * (unsigned)ntiles_j;
+    const bool capa = a.mcapa > 0;
+    if (s->cfg.fwave) return fail(PCL_EINVAL, "fwave: no f-wave Riemann solver is built in yet");
+    if (capa)
+        hipLaunchKernelGGL((sweep_y_kernel<RP, true, false>), dim3(grid), dim3(256), 0, s->stream, a,
+                           ntiles_i);
+    else
+        hipLaunchKernelGGL((sweep_y_kernel<RP, false, false>), dim3(grid), dim3(256), 0, s->stream, a,
+                           ntiles_i);
+    HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+hipEvent_t get_event(pcl_solver *s) {
+    if (!s->evpool.empty()) {
+        hipEvent_t e = s->evpool.back();
+        s->evpool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+int drain_timing(pcl_solver *s) {
+    if (s->timed.empty()) return PCL_OK;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (auto &t : s->timed) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, t.a, t.b);
+        s->kt_ms[t.which] += ms;
+        s->kt_n[t.which] += 1;
+        s->evpool.push_back(t.a);
+        s->evpool.push_back(t.b);
+    }
+    s->timed.clear();
+    return PCL_OK;
+}
+
+// one directional sweep qin -> qout; ids 1 = x (or the 1-D step), 2 = y
+int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt) {
+    const SweepArgs a = make_args(s, qin, qout, ids, dt);
+    pcl_solver::Timed t{};
+    if (s->timing) {
+        t.a = get_event(s);
+        t.b = get_event(s);
+        t.which = ids - 1;
+        hipEventRecord(t.a, s->stream);
+    }
+    int rc = PCL_EINVAL;
+    const int rp = s->cfg.rp;
+    if (s->cfg.ndim == 1) {
+        if (rp == PCL_RP_ADVECTION_1D) rc = launch_x<Advection1D, true>(s, a);
+        else if (rp == PCL_RP_ACOUSTICS_1D) rc = launch_x<Acoustics1D, true>(s, a);
+        else rc = fail(PCL_EINVAL, "Riemann solver id is not a 1-D solver");
+    } else if (ids == 1) {
+        if (rp == PCL_RP_ACOUSTICS_2D) rc = launch_x<Acoustics2D, false>(s, a);
+        else if (rp == PCL_RP_EULER5_2D) rc = launch_x<Euler5, false>(s, a);
+        else rc = fail(PCL_EINVAL, "Riemann solver id is not a 2-D solver");
+    } else {
+        if (rp == PCL_RP_ACOUSTICS_2D) rc = launch_y<Acoustics2D>(s, a);
+        else if (rp == PCL_RP_EULER5_2D) rc = launch_y<Euler5>(s, a);
+        else rc = fail(PCL_EINVAL, "Riemann solver id is not a 2-D solver");
+    }
+    if (s->timing) {
+        hipEventRecord(t.b, s->stream);
+        s->timed.push_back(t);
+        if (s->timed.size() >= 2048) drain_timing(s);
+    }
+    return rc;
+}
+
+int read_cfl(pcl_solver *s, double *cfl) {
+    HIP_TRY(hipMemcpyAsync(s->cfl_host, s->cfl_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    double v;
+    memcpy(&v, s->cfl_host, sizeof(double));
+    *cfl = v;
+    return PCL_OK;
+}
+
+int check_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(PCL_ENODEVICE, "no HIP device available (libpyclaw_amd has no CPU path)");
+    return PCL_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char *pcl_last_error(void) { return g_err.c_str(); }
+int pcl_version(void) { return 100; }
+int pcl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pcl_create(const pcl_config *cfg, pcl_solver **out) {
+    if (!cfg || !out) return fail(PCL_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->ndim < 1 || cfg->ndim > 2) return fail(PCL_EINVAL, "ndim must be 1 or 2");
+    if (cfg->mbc != 2) return fail(PCL_EINVAL, "classic kernels need mbc == 2 (reference default)");
+    if (cfg->mwaves < 1 || cfg->mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
+    if (cfg->math != PCL_MATH_EXACT) return fail(PCL_EINVAL, "unknown math mode");
+    int want_meqn = 0, want_mwaves = 0, want_ndim = 0;
+    switch (cfg->rp) {
+    case PCL_RP_ADVECTION_1D: want_meqn = 1; want_mwaves = 1; want_ndim = 1; break;
+    case PCL_RP_ACOUSTICS_1D: want_meqn = 2; want_mwaves = 2; want_ndim = 1; break;
+    case PCL_RP_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
+    case PCL_RP_EULER5_2D: want_meqn = 5; want_mwaves = 5; want_ndim = 2; break;
+    default: return fail(PCL_EINVAL, "unknown Riemann solver id");
+    }
+    if (cfg->meqn != want_meqn || cfg->mwaves != want_mwaves || cfg->ndim != want_ndim)
+        return fail(PCL_EINVAL, "meqn/mwaves/ndim do not match the Riemann solver");
+    for (int d = 0; d < cfg->ndim; d++)
+        if (cfg->n[d] < 1) return fail(PCL_EINVAL, "grid extent must be >= 1");
+    if (cfg->method[5] < 0 || cfg->method[5] > cfg->maux) return fail(PCL_EINVAL, "mcapa out of range");
+    if (int rc = check_device()) return rc;
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    pcl_solver *s = new pcl_solver();
+    s->cfg = *cfg;
+    s->I = cfg->n[0] + 2 * cfg->mbc;
+    s->J = cfg->ndim > 1 ? cfg->n[1] + 2 * cfg->mbc : 1;
+    s->pitch = ((long)s->I + 15) / 16 * 16;
+    s->plane = s->pitch * s->J;
+    s->total = s->plane * cfg->meqn;
+    const size_t qbytes = (size_t)s->total * sizeof(double);
+    hipError_t e = hipSuccess;
+    auto alloc = [&](double **p, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = hipMalloc((void **)p, bytes);
+        if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+    };
+    alloc(&s->q, qbytes);
+    alloc(&s->t1, qbytes);
+    if (cfg->ndim > 1) alloc(&s->t2, qbytes);
+    if (cfg->maux > 0) alloc(&s->aux, (size_t)s->plane * cfg->maux * sizeof(double));
+    const int nmax = cfg->meqn > cfg->maux ? cfg->meqn : cfg->maux;
+    s->stage_bytes = (size_t)nmax * s->I * s->J * sizeof(double);
+    alloc(&s->stage, s->stage_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->cfl_dev, 64);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->cfl_host, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e != hipSuccess) {
+        std::string msg = std::string("pcl_create: ") + hipGetErrorString(e);
+        pcl_destroy(s);
+        return fail(PCL_EHIP, msg);
+    }
+    *out = s;
+    return PCL_OK;
+}
+
+void pcl_destroy(pcl_solver *s) {
+    if (!s) return;
+    hipSetDevice(s->cfg.device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    s->halo.destroy();
+    for (auto &t : s->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (auto &e : s->evpool) hipEventDestroy(e);
+    hipFree(s->q); hipFree(s->t1); hipFree(s->t2); hipFree(s->bak); hipFree(s->aux);
+    hipFree(s->stage); hipFree(s->cfl_dev);
+    if (s->cfl_host) hipHostFree(s->cfl_host);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+static int put_array(pcl_solver *s, const double *host, double *dev, int nm, int with_ghosts) {
+    const int mbc = s->cfg.mbc;
+    const int ni = with_ghosts ? s->I : s->cfg.n[0];
+    const int nj = s->cfg.ndim > 1 ? (with_ghosts ? s->J : s->cfg.n[1]) : 1;
+    const int io = with_ghosts ? 0 : mbc;
+    const int jo = (s->cfg.ndim > 1 && !with_ghosts) ? mbc : 0;
+    const size_t bytes = (size_t)nm * ni * nj * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(s->stage, host, bytes, hipMemcpyHostToDevice, s->stream));
+    dim3 grid((ni + 255) / 256, nj);
+    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, dev, nm, ni, nj, io, jo,
+                       s->pitch, s->plane);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PCL_OK;
+}
+
+int pcl_put_q(pcl_solver *s, const double *host, int with_ghosts) {
+    if (!s || !host) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    s->undo_slot = nullptr;
+    return put_array(s, host, s->q, s->cfg.meqn, with_ghosts);
+}
+
+int pcl_put_aux(pcl_solver *s, const double *host) {
+    if (!s || !host) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.maux <= 0) return fail(PCL_EINVAL, "solver was created with maux == 0");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    return put_array(s, host, s->aux, s->cfg.maux, 1);
+}
+
+int pcl_get_q(pcl_solver *s, double *host, int with_ghosts) {
+    if (!s || !host) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    const int mbc = s->cfg.mbc, nm = s->cfg.meqn;
+    const int ni = with_ghosts ? s->I : s->cfg.n[0];
+    const int nj = s->cfg.ndim > 1 ? (with_ghosts ? s->J : s->cfg.n[1]) : 1;
+    const int io = with_ghosts ? 0 : mbc;
+    const int jo = (s->cfg.ndim > 1 && !with_ghosts) ? mbc : 0;
+    const size_t bytes = (size_t)nm * ni * nj * sizeof(double);
+    dim3 grid((ni + 255) / 256, nj);
+    hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, s->q, s->stage, nm, ni, nj, io, jo,
+                       s->pitch, s->plane);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PCL_OK;
+}
+
+static int strip_window(pcl_solver *s, int idim, int side, int width, int &ni, int &nj, int &io,
+                        int &jo) {
+    if (idim < 0 || idim >= s->cfg.ndim) return fail(PCL_EINVAL, "bad idim");
+    const int N = idim == 0 ? s->I : s->J;
+    if (width < 1 || width > N) return fail(PCL_EINVAL, "bad strip width");
+    ni = s->I; nj = s->J; io = 0; jo = 0;
+    if (idim == 0) { ni = width; io = side == 0 ? 0 : N - width; }
+    else { nj = width; jo = side == 0 ? 0 : N - width; }
+    return PCL_OK;
+}
+
+int pcl_get_strip(pcl_solver *s, int idim, int side, int width, double *host) {
+    if (!s || !host) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    int ni, nj, io, jo;
+    if (int rc = strip_window(s, idim, side, width, ni, nj, io, jo)) return rc;
+    const int nm = s->cfg.meqn;
+    dim3 grid((ni + 255) / 256, nj);
+    hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, s->q, s->stage, nm, ni, nj, io, jo,
+                       s->pitch, s->plane);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, s->stage, (size_t)nm * ni * nj * sizeof(double), hipMemcpyDeviceToHost,
+                           s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PCL_OK;
+}
+
+int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *host) {
+    if (!s || !host) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    int ni, nj, io, jo;
+    if (int rc = strip_window(s, idim, side, width, ni, nj, io, jo)) return rc;
+    const int nm = s->cfg.meqn;
+    HIP_TRY(hipMemcpyAsync(s->stage, host, (size_t)nm * ni * nj * sizeof(double), hipMemcpyHostToDevice,
+                           s->stream));
+    dim3 grid((ni + 255) / 256, nj);
+    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, s->q, nm, ni, nj, io, jo,
+                       s->pitch, s->plane);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PCL_OK;
+}
+
+static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate) {
+    const int nt = idim == 0 ? s->J : s->I;
+    const long n = (long)nt * s->cfg.mbc * s->cfg.meqn;
+    hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->q,
+                       s->cfg.meqn, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, idim, side, type, cstate);
+    HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_bc(pcl_solver *s, int idim, int side, int bctype) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (idim < 0 || idim >= s->cfg.ndim || side < 0 || side > 1) return fail(PCL_EINVAL, "bad idim/side");
+    if (bctype != PCL_BC_OUTFLOW && bctype != PCL_BC_PERIODIC && bctype != PCL_BC_REFLECTING)
+        return fail(PCL_EINVAL, "pcl_bc: only outflow/periodic/reflecting run here");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    return bc_launch(s, idim, side, bctype, nullptr);
+}
+
+int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state) {
+    if (!s || !state) return fail(PCL_EINVAL, "null argument");
+    if (idim < 0 || idim >= s->cfg.ndim || side < 0 || side > 1) return fail(PCL_EINVAL, "bad idim/side");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    // constants travel through the pinned cfl page's tail? no: a tiny device scratch at stage head
+    HIP_TRY(hipMemcpyAsync(s->stage, state, sizeof(double) * s->cfg.meqn, hipMemcpyHostToDevice,
+                           s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));  // `state` may be a temporary
+    return bc_launch(s, idim, side, 100, s->stage);
+}
+
+int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl) {
+    if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
+    if (ids < 1 || ids > s->cfg.ndim) return fail(PCL_EINVAL, "bad ids");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
+    if (int rc = do_sweep(s, s->q, s->t1, ids, dt)) return rc;
+    std::swap(s->q, s->t1);
+    s->undo_slot = &s->t1;
+    return read_cfl(s, cfl);
+}
+
+int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
+    if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
+    if (s->cfg.ndim == 1) {
+        if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return rc;
+        std::swap(s->q, s->t1);
+        s->undo_slot = &s->t1;
+    } else if (s->cfg.method[2] < 0) {  // dimensional splitting, clawpack.py:538-546
+        if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return rc;
+        if (int rc = do_sweep(s, s->t1, s->t2, 2, dt)) return rc;
+        std::swap(s->q, s->t2);
+        s->undo_slot = &s->t2;
+    } else {
+        return fail(PCL_EINVAL, "unsplit step2 (dim_split=False) is not implemented yet");
+    }
+    return read_cfl(s, cfl);
+}
+
+int pcl_undo_step(pcl_solver *s) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (!s->undo_slot) return fail(PCL_ESTATE, "no step to undo");
+    std::swap(s->q, *s->undo_slot);
+    s->undo_slot = nullptr;
+    return PCL_OK;
+}
+
+int pcl_backup(pcl_solver *s) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    const size_t qbytes = (size_t)s->total * sizeof(double);
+    if (!s->bak) HIP_TRY(hipMalloc((void **)&s->bak, qbytes));
+    HIP_TRY(hipMemcpyAsync(s->bak, s->q, qbytes, hipMemcpyDeviceToDevice, s->stream));
+    return PCL_OK;
+}
+
+int pcl_restore(pcl_solver *s) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (!s->bak) return fail(PCL_ESTATE, "pcl_restore without pcl_backup");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipMemcpyAsync(s->q, s->bak, (size_t)s->total * sizeof(double), hipMemcpyDeviceToDevice,
+                           s->stream));
+    s->undo_slot = nullptr;
+    return PCL_OK;
+}
+
+int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int nparams) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    if (src_id == PCL_SRC_EULER_RADIAL) {
+        if (s->cfg.rp != PCL_RP_EULER5_2D || s->cfg.maux < 1 || nparams < 2 || !params)
+            return fail(PCL_EINVAL, "euler radial source needs the Euler solver, aux[0]=radius, {gamma1,ndim}");
+        dim3 grid((s->cfg.n[0] + 255) / 256, s->cfg.n[1]);
+        hipLaunchKernelGGL(src_euler_radial, grid, dim3(256), 0, s->stream, s->q, s->aux, s->cfg.mbc,
+                           s->cfg.n[0], s->cfg.n[1], s->pitch, s->plane, dt, params[0], params[1] - 1.0);
+        HIP_TRY(hipGetLastError());
+        return PCL_OK;
+    }
+    return fail(PCL_EINVAL, "unknown source id");
+}
+
+int pcl_sync(pcl_solver *s) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PCL_OK;
+}
+
+int pcl_timer_start(pcl_solver *s) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    return PCL_OK;
+}
+int pcl_timer_stop(pcl_solver *s, float *ms) {
+    if (!s || !ms) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return PCL_OK;
+}
+int pcl_kernel_timing(pcl_solver *s, int enable) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (int rc = drain_timing(s)) return rc;
+    s->timing = enable != 0;
+    s->kt_ms[0] = s->kt_ms[1] = 0;
+    s->kt_n[0] = s->kt_n[1] = 0;
+    return PCL_OK;
+}
+int pcl_kernel_timing_read(pcl_solver *s, double *ms_total, long *launches) {
+    if (!s || !ms_total || !launches) return fail(PCL_EINVAL, "null argument");
+    if (int rc = drain_timing(s)) return rc;
+    ms_total[0] = s->kt_ms[0]; ms_total[1] = s->kt_ms[1];
+    launches[0] = s->kt_n[0]; launches[1] = s->kt_n[1];
+    return PCL_OK;
+}
+
+int pcl_debug_wave_shift(const double *in64, double *left64, double *right64) {
+    if (int rc = check_device()) return rc;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 3 * 64 * sizeof(double)));
+    HIP_TRY(hipMemcpy(d, in64, 64 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(shift_test_kernel, dim3(1), dim3(64), 0, 0, d, d + 64, d + 128);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(left64, d + 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(right64, d + 128, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(d);
+    return PCL_OK;
+}
+
+// ---- layer 1: f2py-shaped host calls -------------------------------------------------------------
+static int host_sweep(int ndim, int rp, const double *rp_params, int fwave, int meqn, int mwaves,
+                      int maux, int mbc, int mx, int my, const double *qold, double *qnew,
+                      const double *aux, double dx, double dy, double dt, const int *method,
+                      const int *mthlim, double *cfl, int ids, bool unsplit) {
+    if (!qold || !qnew || !method || !mthlim || !cfl) return fail(PCL_EINVAL, "null argument");
+    pcl_config c;
+    memset(&c, 0, sizeof(c));
+    c.ndim = ndim; c.n[0] = mx; c.n[1] = my; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves;
+    c.maux = method[6];
+    (void)maux;
+    for (int k = 0; k < 7; k++) c.method[k] = method[k];
+    if (mwaves < 1 || mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
+    for (int k = 0; k < mwaves; k++) c.mthlim[k] = mthlim[k];
+    c.fwave = fwave; c.rp = rp;
+    if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
+    c.d[0] = dx; c.d[1] = dy; c.device = 0; c.math = PCL_MATH_EXACT;
+    pcl_solver *s = nullptr;
+    if (int rc = pcl_create(&c, &s)) return rc;
+    int rc = pcl_put_q(s, qold, 1);
+    if (!rc && c.maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
+    if (!rc) rc = unsplit ? pcl_step_hyperbolic(s, dt, cfl) : pcl_sweep(s, ids, dt, cfl);
+    if (!rc) rc = pcl_get_q(s, qnew, 1);
+    pcl_destroy(s);
+    return rc;
+}
+
+int pcl_step1(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx,
+              double *q, const double *aux, double dx, double dt, const int *method,
+              const int *mthlim, double *cfl) {
+    return host_sweep(1, rp, rp_params, 0, meqn, mwaves, maux, mbc, mx, 1, q, q, aux, dx, 1.0, dt,
+                      method, mthlim, cfl, 1, false);
+}
+
+int pcl_step2ds(int rp, const double *rp_params, int fwave, int meqn, int mwaves, int maux, int mbc,
+                int mx, int my, const double *qold, double *qnew, const double *aux, double dx,
+                double dy, double dt, const int *method, const int *mthlim, double *cfl, int ids) {
+    if (ids != 1 && ids != 2) return fail(PCL_EINVAL, "ids must be 1 or 2");
+    return host_sweep(2, rp, rp_params, fwave, meqn, mwaves, maux, mbc, mx, my, qold, qnew, aux, dx, dy,
+                      dt, method, mthlim, cfl, ids, false);
+}
+
+int pcl_step2(int rp, const double *rp_params, int fwave, int meqn, int mwaves, int maux, int mbc,
+              int mx, int my, const double *qold, double *qnew, const double *aux, double dx, double dy,
+              double dt, const int *method, const int *mthlim, double *cfl) {
+    if (!method || method[2] < 0) return fail(PCL_EINVAL, "step2 needs method[2] >= 0 (unsplit)");
+    return host_sweep(2, rp, rp_params, fwave, meqn, mwaves, maux, mbc, mx, my, qold, qnew, aux, dx, dy,
+                      dt, method, mthlim, cfl, 0, true);
+}
+
+// ---- multi-GPU -----------------------------------------------------------------------------------
+int pcl_comm_unique_id(char uid[128]) {
+    std::string err;
+    if (pcl::Halo::unique_id(uid, err)) return fail(PCL_ECOMM, err);
+    return PCL_OK;
+}
+
+int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], const int neighbors[8]) {
+    if (!s || !uid || !neighbors) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.ndim != 2) return fail(PCL_EINVAL, "halo exchange is implemented for 2-D blocks");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    std::string err;
+    const int nmax = s->cfg.meqn > s->cfg.maux ? s->cfg.meqn : s->cfg.maux;
+    if (s->halo.init(nranks, rank, uid, neighbors, s->I, s->J, s->cfg.mbc, nmax, s->stream, err))
+        return fail(PCL_ECOMM, err);
+    return PCL_OK;
+}
+
+int pcl_halo_exchange(pcl_solver *s) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    std::string err;
+    if (s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);
+    return PCL_OK;
+}
+
+int pcl_halo_exchange_aux(pcl_solver *s) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.maux <= 0) return PCL_OK;
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    std::string err;
+    if (s->halo.exchange(s->aux, s->cfg.maux, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);
+    return PCL_OK;
+}
+
+int pcl_allreduce_max(pcl_solver *s, double *value) {
+    if (!s || !value) return fail(PCL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    std::string err;
+    if (s->halo.allreduce_max(value, err)) return fail(PCL_ECOMM, err);
+    return PCL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+// rp.hpp -- pointwise Riemann solvers as device functions (gfx950).
+//
+// The reference's "vectorised" solvers loop over a slice and write slice arrays
+// (rpn2(ixy,maxm,meqn,mwaves,mbc,mx,ql,qr,auxl,auxr,wave,s,amdq,apdq)); here one
+// lane owns one interface and everything stays in registers.  Per-CELL quantities
+// that the Fortran recomputes for the interface on either side of a cell
+// (pressure, sqrt(rho), sound speed ...) are computed once per lane in precell()
+// and handed to the right-hand neighbour with a wavefront shift.  Each expression
+// keeps the reference's operation order so PCL_MATH_EXACT is bit-identical.
+//
+// Solver concept:
+//   MEQN, MWAVES, NCELL (doubles in Cell)
+//   template<int IXY> nz(mw,m)  -- compile-time sparsity of wave(m,mw)
+//   template<int IXY> precell(q, par) -> Cell
+//   template<int IXY> solve(L, R, par, wave, s, amdq, apdq)
+//   template<int IXY> transverse(L, R, par, asdq, bmasdq, bpasdq)   (rpt2)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pcl {
+
+struct RpParams {
+    double v[8];
+};
+
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+
+// ------------------------------------------------------------------------------------
+// 1-D advection, q_t + u q_x = 0  (third-party rp1_advection.f, restated)
+// ------------------------------------------------------------------------------------
+struct Advection1D {
+    static constexpr int MEQN = 1, MWAVES = 1, NCELL = 1;
+    struct Cell { double q[1]; };
+    template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &) {
+        Cell c; c.q[0] = q[0]; return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &p,
+                                                 double (&wave)[1][1], double (&s)[1],
+                                                 double (&amdq)[1], double (&apdq)[1]) {
+        const double u = p.v[0];
+        wave[0][0] = R.q[0] - L.q[0];
+        s[0] = u;
+        amdq[0] = dmin(u, 0.0) * wave[0][0];
+        apdq[0] = dmax(u, 0.0) * wave[0][0];
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// 1-D acoustics (third-party rp1_acoustics.f, restated); par = rho,bulk,cc,zz
+// ------------------------------------------------------------------------------------
+struct Acoustics1D {
+    static constexpr int MEQN = 2, MWAVES = 2, NCELL = 2;
+    struct Cell { double q[2]; };
+    template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &) {
+        Cell c; c.q[0] = q[0]; c.q[1] = q[1]; return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &p,
+                                                 double (&wave)[2][2], double (&s)[2],
+                                                 double (&amdq)[2], double (&apdq)[2]) {
+        const double cc = p.v[2], zz = p.v[3];
+        const double d1 = R.q[0] - L.q[0];
+        const double d2 = R.q[1] - L.q[1];
+        const double a1 = (-d1 + zz * d2) / (2.0 * zz);
+        const double a2 = (d1 + zz * d2) / (2.0 * zz);
+        wave[0][0] = -a1 * zz; wave[0][1] = a1; s[0] = -cc;
+        wave[1][0] = a2 * zz;  wave[1][1] = a2; s[1] = cc;
+        for (int m = 0; m < 2; m++) { amdq[m] = s[0] * wave[0][m]; apdq[m] = s[1] * wave[1][m]; }
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// 2-D acoustics (third-party rpn2_acoustics.f / rpt2_acoustics.f, restated)
+// q = (p, u, v); par = rho,bulk,cc,zz
+// ------------------------------------------------------------------------------------
+struct Acoustics2D {
+    static constexpr int MEQN = 3, MWAVES = 2, NCELL = 3;
+    struct Cell { double q[3]; };
+    template <int IXY> __device__ static constexpr bool nz(int /*mw*/, int m) {
+        return m == 0 || m == (IXY == 1 ? 1 : 2);
+    }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &) {
+        Cell c; c.q[0] = q[0]; c.q[1] = q[1]; c.q[2] = q[2]; return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &p,
+                                                 double (&wave)[2][3], double (&s)[2],
+                                                 double (&amdq)[3], double (&apdq)[3]) {
+        constexpr int mu = (IXY == 1) ? 1 : 2, mv = (IXY == 1) ? 2 : 1;
+        const double cc = p.v[2], zz = p.v[3];
+        const double d1 = R.q[0] - L.q[0];
+        const double d2 = R.q[mu] - L.q[mu];
+        const double a1 = (-d1 + zz * d2) / (2.0 * zz);
+        const double a2 = (d1 + zz * d2) / (2.0 * zz);
+        wave[0][0] = -a1 * zz; wave[0][mu] = a1; wave[0][mv] = 0.0; s[0] = -cc;
+        wave[1][0] = a2 * zz;  wave[1][mu] = a2; wave[1][mv] = 0.0; s[1] = cc;
+        for (int m = 0; m < 3; m++) { amdq[m] = s[0] * wave[0][m]; apdq[m] = s[1] * wave[1][m]; }
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void transverse(const Cell &, const Cell &, const RpParams &p,
+                                                      const double (&asdq)[3], double (&bm)[3],
+                                                      double (&bp)[3]) {
+        constexpr int mu = (IXY == 1) ? 1 : 2, mv = (IXY == 1) ? 2 : 1;
+        const double cc = p.v[2], zz = p.v[3];
+        const double a1 = (-asdq[0] + zz * asdq[mv]) / (2.0 * zz);
+        const double a2 = (asdq[0] + zz * asdq[mv]) / (2.0 * zz);
+        bm[0] = cc * a1 * zz; bm[mu] = 0.0; bm[mv] = -cc * a1;
+        bp[0] = cc * a2 * zz; bp[mu] = 0.0; bp[mv] = cc * a2;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// 2-D Euler, Roe solver with 5 waves (acoustic-, shear, entropy, acoustic+, tracer) and
+// the Harten-Hyman entropy fix: development/rp_approaches/rpn2_euler_5wave.f:87-298,
+// transverse split rpt2_euler_5wave_rec_loc.f:50-116.  par = gamma, gamma1.
+// ------------------------------------------------------------------------------------
+struct Euler5 {
+    static constexpr int MEQN = 5, MWAVES = 5, NCELL = 12;
+    struct Cell {
+        double q[5];
+        double rs;      // sqrt(rho)                       rpn2:88-89
+        double p;       // pressure                        rpn2:90-93 == :211-212,260-261
+        double qu_rs;   // q(mu)/sqrt(rho)                 rpn2:95
+        double qv_rs;   // q(mv)/sqrt(rho)                 rpn2:96
+        double h_rs;    // (E+p)/sqrt(rho)                 rpn2:97-98
+        double c;       // sqrt(gamma*p/rho)               rpn2:213,262
+        double un;      // q(mu)/rho                       rpn2:214,263
+    };
+    // wave(m,mw) sparsity, rpn2:124-163
+    template <int IXY> __device__ static constexpr bool nz(int mw, int m) {
+        constexpr int mv = (IXY == 1) ? 2 : 1;
+        return mw == 1 ? (m == mv || m == 3) : mw == 4 ? (m == 4) : (m != 4);
+    }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &par) {
+        constexpr int mu = (IXY == 1) ? 1 : 2, mv = (IXY == 1) ? 2 : 1;
+        const double gamma = par.v[0], gamma1 = par.v[1];
+        Cell c;
+        for (int m = 0; m < 5; m++) c.q[m] = q[m];
+        c.rs = sqrt(q[0]);
+        c.p = gamma1 * (q[3] - 0.5 * (q[1] * q[1] + q[2] * q[2]) / q[0]);
+        c.qu_rs = q[mu] / c.rs;
+        c.qv_rs = q[mv] / c.rs;
+        c.h_rs = (q[3] + c.p) / c.rs;
+        c.c = sqrt(gamma * c.p / q[0]);
+        c.un = q[mu] / q[0];
+        return c;
+    }
+    struct Roe { double u, v, enth, a, g1a2, euv, u2v2; };
+    __device__ static __forceinline__ Roe roe(const Cell &L, const Cell &R, double gamma1) {
+        Roe r;
+        const double rhsq2 = L.rs + R.rs;
+        r.u = (L.qu_rs + R.qu_rs) / rhsq2;
+        r.v = (L.qv_rs + R.qv_rs) / rhsq2;
+        r.enth = (L.h_rs + R.h_rs) / rhsq2;
+        r.u2v2 = r.u * r.u + r.v * r.v;
+        const double a2 = gamma1 * (r.enth - .5 * r.u2v2);
+        r.a = sqrt(a2);
+        r.g1a2 = gamma1 / a2;
+        r.euv = r.enth - r.u2v2;
+        return r;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &par,
+                                                 double (&wave)[5][5], double (&s)[5],
+                                                 double (&amdq)[5], double (&apdq)[5]) {
+        constexpr int mu = (IXY == 1) ? 1 : 2, mv = (IXY == 1) ? 2 : 1;
+        const double gamma = par.v[0], gamma1 = par.v[1];
+        const Roe r = roe(L, R, gamma1);
+        const double u = r.u, v = r.v, enth = r.enth, a = r.a;
+        const double delta1 = R.q[0] - L.q[0];
+        const double delta2 = R.q[mu] - L.q[mu];
+        const double delta3 = R.q[mv] - L.q[mv];
+        const double delta4 = R.q[3] - L.q[3];
+        const double a3 = r.g1a2 * (r.euv * delta1 + u * delta2 + v * delta3 - delta4);
+        const double a2 = delta3 - v * delta1;
+        const double a4 = (delta2 + (a - u) * delta1 - a * a3) / (2.0 * a);
+        const double a1 = delta1 - a3 - a4;
+
+        wave[0][0] = a1; wave[0][mu] = a1 * (u - a); wave[0][mv] = a1 * v;
+        wave[0][3] = a1 * (enth - u * a); wave[0][4] = 0.0; s[0] = u - a;
+        wave[1][0] = 0.0; wave[1][mu] = 0.0; wave[1][mv] = a2;
+        wave[1][3] = a2 * v; wave[1][4] = 0.0; s[1] = u;
+        wave[2][0] = a3; wave[2][mu] = a3 * u; wave[2][mv] = a3 * v;
+        wave[2][3] = a3 * 0.5 * r.u2v2; wave[2][4] = 0.0; s[2] = u;
+        wave[3][0] = a4; wave[3][mu] = a4 * (u + a); wave[3][mv] = a4 * v;
+        wave[3][3] = a4 * (enth + u * a); wave[3][4] = 0.0; s[3] = u + a;
+        wave[4][0] = 0.0; wave[4][mu] = 0.0; wave[4][mv] = 0.0; wave[4][3] = 0.0;
+        wave[4][4] = R.q[4] - L.q[4]; s[4] = u;
+
+        // ---- entropy fix (rpn2:205-286).  The early exits of the Fortran become flags.
+        const double s0 = L.un - L.c;                       // u-c in left state
+        const bool all_right = (s0 >= 0.0) && (s[0] > 0.0); // rpn2:217
+        {
+            const double rho1 = L.q[0] + wave[0][0];
+            const double rhou1 = L.q[mu] + wave[0][mu];
+            const double rhov1 = L.q[mv] + wave[0][mv];
+            const double en1 = L.q[3] + wave[0][3];
+            const double p1 = gamma1 * (en1 - 0.5 * (rhou1 * rhou1 + rhov1 * rhov1) / rho1);
+            const double c1 = sqrt(gamma * p1 / rho1);
+            const double s1 = rhou1 / rho1 - c1;
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0)
+                sfract = s0 * (s1 - s[0]) / (s1 - s0);
+            else if (s[0] < 0.0)
+                sfract = s[0];
+            else
+                sfract = 0.0;
+            for (int m = 0; m < 5; m++) amdq[m] = sfract * wave[0][m];
+        }
+        if (!(s[1] >= 0.0)) {                                // rpn2:249
+            for (int m = 0; m < 5; m++) {
+                if (nz<IXY>(1, m)) amdq[m] = amdq[m] + s[1] * wave[1][m];
+                if (nz<IXY>(2, m)) amdq[m] = amdq[m] + s[2] * wave[2][m];
+                if (nz<IXY>(4, m)) amdq[m] = amdq[m] + s[4] * wave[4][m];
+            }
+            const double s3 = R.un + R.c;                    // u+c in right state
+            const double rho2 = R.q[0] - wave[3][0];
+            const double rhou2 = R.q[mu] - wave[3][mu];
+            const double rhov2 = R.q[mv] - wave[3][mv];
+            const double en2 = R.q[3] - wave[3][3];
+            const double p2 = gamma1 * (en2 - 0.5 * (rhou2 * rhou2 + rhov2 * rhov2) / rho2);
+            const double c2 = sqrt(gamma * p2 / rho2);
+            const double s2 = rhou2 / rho2 + c2;
+            double sfract = 0.0;
+            bool add4 = true;
+            if (s2 < 0.0 && s3 > 0.0)
+                sfract = s2 * (s3 - s[3]) / (s3 - s2);
+            else if (s[3] < 0.0)
+                sfract = s[3];
+            else
+                add4 = false;
+            if (add4)
+                for (int m = 0; m < 4; m++) amdq[m] = amdq[m] + sfract * wave[3][m];
+        }
+        if (all_right)
+            for (int m = 0; m < 5; m++) amdq[m] = 0.0;
+
+        // apdq = sum_mw s*wave - amdq  (rpn2:291-298), zero wave entries skipped
+        for (int m = 0; m < 5; m++) {
+            double df = 0.0;
+            for (int mw = 0; mw < 5; mw++)
+                if (nz<IXY>(mw, m)) df = df + s[mw] * wave[mw][m];
+            apdq[m] = df - amdq[m];
+        }
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void transverse(const Cell &L, const Cell &R,
+                                                      const RpParams &par, const double (&asdq)[5],
+                                                      double (&bm)[5], double (&bp)[5]) {
+        constexpr int mu = (IXY == 1) ? 1 : 2, mv = (IXY == 1) ? 2 : 1;
+        const double gamma1 = par.v[1];
+        const Roe r = roe(L, R, gamma1);
+        const double u = r.u, v = r.v, enth = r.enth, a = r.a;
+        const double a3 = r.g1a2 * (r.euv * asdq[0] + u * asdq[mu] + v * asdq[mv] - asdq[3]);
+        const double a2 = asdq[mu] - u * asdq[0];
+        const double a4 = (asdq[mv] + (a - v) * asdq[0] - a * a3) / (2.0 * a);
+        const double a1 = asdq[0] - a3 - a4;
+        double wb[4][5], sb[4];
+        wb[0][0] = a1; wb[0][mu] = a1 * u; wb[0][mv] = a1 * (v - a);
+        wb[0][3] = a1 * (enth - v * a); wb[0][4] = 0.0; sb[0] = v - a;
+        wb[1][0] = a3; wb[1][mu] = a3 * u + a2; wb[1][mv] = a3 * v;
+        wb[1][3] = a3 * 0.5 * r.u2v2 + a2 * u; wb[1][4] = 0.0; sb[1] = v;
+        wb[2][0] = a4; wb[2][mu] = a4 * u; wb[2][mv] = a4 * (v + a);
+        wb[2][3] = a4 * (enth + v * a); wb[2][4] = 0.0; sb[2] = v + a;
+        wb[3][0] = 0.0; wb[3][mu] = 0.0; wb[3][mv] = 0.0; wb[3][3] = 0.0;
+        wb[3][4] = asdq[4]; sb[3] = v;
+        for (int m = 0; m < 5; m++) {
+            double m_ = 0.0, p_ = 0.0;
+            for (int mw = 0; mw < 4; mw++) {
+                m_ = m_ + dmin(sb[mw], 0.0) * wb[mw][m];
+                p_ = p_ + dmax(sb[mw], 0.0) * wb[mw][m];
+            }
+            bm[m] = m_; bp[m] = p_;
+        }
+    }
+};
+
+}  // namespace pcl

@@ -1,0 +1,50 @@
+"""
+Riemann solver registry.
+
+The reference picks the Riemann solver when the app's f2py module is linked
+(``apps/*/Makefile``: ``$(RIEMANN)/src/rpn2_*.f``) and hands its scalars over through the
+``cparam`` common block filled from ``state.aux_global`` (src/pyclaw/state.py:142-162).
+Here a solver is named on the Solver object (``solver.rp = riemann.rp_euler_5wave_2d`` or
+the string ``'euler_5wave_2d'``); ``cparam`` lists the aux_global keys in common-block order.
+"""
+
+
+class RiemannSolver(object):
+    def __init__(self, name, rp_id, ndim, meqn, mwaves, cparam, has_transverse=False):
+        self.name = name
+        self.id = rp_id
+        self.ndim = ndim
+        self.meqn = meqn
+        self.mwaves = mwaves
+        self.cparam = tuple(cparam)
+        self.has_transverse = has_transverse
+
+    def params(self, aux_global):
+        """cparam values from aux_global; same check as State.set_cparam (state.py:156-160)."""
+        if not set(self.cparam) <= set(aux_global.keys()):
+            raise Exception("""Some required value(s) in the cparam common 
+                                   block in the Riemann solver have not been 
+                                   set in aux_global.""")
+        return [float(aux_global[k]) for k in self.cparam]
+
+    def __repr__(self):
+        return "<RiemannSolver %s>" % self.name
+
+
+rp_advection_1d = RiemannSolver("advection_1d", 1, 1, 1, 1, ["u"])
+rp_acoustics_1d = RiemannSolver("acoustics_1d", 2, 1, 2, 2, ["rho", "bulk", "cc", "zz"])
+rp_acoustics_2d = RiemannSolver("acoustics_2d", 10, 2, 3, 2, ["rho", "bulk", "cc", "zz"], True)
+rp_euler_5wave_2d = RiemannSolver("euler_5wave_2d", 11, 2, 5, 5, ["gamma", "gamma1"], True)
+
+_ALL = [rp_advection_1d, rp_acoustics_1d, rp_acoustics_2d, rp_euler_5wave_2d]
+BY_NAME = dict((r.name, r) for r in _ALL)
+
+
+def get(rp):
+    if isinstance(rp, RiemannSolver):
+        return rp
+    if isinstance(rp, str):
+        key = rp[3:] if rp.startswith("rp_") else rp
+        if key in BY_NAME:
+            return BY_NAME[key]
+    raise Exception("Unknown Riemann solver %r; available: %s" % (rp, sorted(BY_NAME)))

@@ -1,0 +1,399 @@
+r"""
+Solver base class: the plugin surface of the reference (src/pyclaw/solver.py).
+
+``evolve_to_time`` / ``step`` / ``setup`` / ``teardown`` keep the reference's semantics
+(adaptive dt with CFL accept/reject and retake, solver.py:602-717; status dict; error
+messages).  What differs is where the state lives: between the first and last line of
+``evolve_to_time`` the authoritative ``q`` is the solver's resident copy in HBM; ``state.q`` on
+the host is refreshed when control returns to the caller (and around user callbacks that
+are plain Python).  The reference's ``q_backup = state.q.copy('F')`` (solver.py:660) becomes
+a pointer swap on the device (``pcl_undo_step``) -- no copy at all in the common case.
+"""
+import logging
+
+import numpy as np
+
+from . import _lib, parallel
+from .cfl import CFL
+
+
+class BC():
+    """Boundary condition types (solver.py:17-23)."""
+    custom = 0
+    outflow = 1
+    periodic = 2
+    reflecting = 3
+
+
+class DeviceBC(object):
+    """A user boundary condition that libpyclaw_amd applies on the device.
+
+    Assign an instance to ``solver.user_bc_lower`` / ``user_bc_upper`` (with the matching
+    ``bc_lower[idim] = BC.custom``) instead of a Python function to avoid moving ghost cells
+    through the host every step.
+    """
+
+    def apply(self, solver, idim, side):
+        raise NotImplementedError
+
+
+class ConstantStateBC(DeviceBC):
+    """Ghost cells of one side := a fixed state vector (e.g. the post-shock inflow state of
+    test/euler/2d/shockbubble.py:41-57).  ``dims`` restricts it to some dimensions."""
+
+    def __init__(self, state, dims=None):
+        self.state = np.ascontiguousarray(state, dtype=np.float64)
+        self.dims = dims
+
+    def apply(self, solver, idim, side):
+        if self.dims is not None and idim not in self.dims:
+            return
+        _lib.check(_lib.lib().pcl_bc_const(solver._h, idim, side, _lib.d(self.state)))
+
+
+class Solver(object):
+    r"""Pyclaw solver superclass; see the reference docstring (solver.py:25-125)."""
+
+    _required_attrs = ['dt_initial', 'dt_max', 'cfl_max', 'cfl_desired', 'max_steps', 'dt_variable',
+                       'mbc']
+    _default_attr_values = {'dt_initial': 0.1, 'dt_max': 1e99, 'max_steps': 1000, 'dt_variable': True}
+
+    def __init__(self, data=None):
+        self.logger = logging.getLogger('evolve')
+        # class-level defaults may be extended by subclasses before calling this
+        for (k, v) in self._default_attr_values.items():
+            self.__dict__.setdefault(k, v)
+        if data is not None:
+            for attr in self._required_attrs:
+                if hasattr(data, attr):
+                    setattr(self, attr, getattr(data, attr))
+
+        self.dt = self._default_attr_values['dt_initial']
+        self.cfl = CFL(self._default_attr_values['cfl_desired'])
+        self.status = {'cflmax': self.cfl.get_cached_max(), 'dtmin': self.dt, 'dtmax': self.dt,
+                       'numsteps': 0}
+        self.bc_lower = [None] * self.ndim
+        self.bc_upper = [None] * self.ndim
+        self.aux_bc_lower = [None] * self.ndim
+        self.aux_bc_upper = [None] * self.ndim
+        self.user_bc_lower = None
+        self.user_bc_upper = None
+        self.user_aux_bc_lower = None
+        self.user_aux_bc_upper = None
+        self.compute_gauge_values = None
+        self.qbc = None
+        self.auxbc = None
+        # device handle (libpyclaw_amd) and bookkeeping
+        self._h = None
+        self._resident = False       # True while the HBM copy is the authoritative q
+        self._host_stale = False
+        self._state = None
+
+    # ------------------------------------------------------------------ validation
+    def is_valid(self):
+        valid = True
+        for key in self._required_attrs:
+            if key not in self.__dict__:
+                self.logger.info('%s is not present.' % key)
+                valid = False
+        if any(b == BC.custom for b in self.bc_lower) and self.user_bc_lower is None:
+            valid = False
+        if any(b == BC.custom for b in self.bc_upper) and self.user_bc_upper is None:
+            valid = False
+        return valid
+
+    def setup(self, solution):
+        pass
+
+    def teardown(self):
+        self._release()
+
+    def _release(self):
+        if self._h is not None:
+            _lib.lib().pcl_destroy(self._h)
+            self._h = None
+        self._resident = False
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def __str__(self):
+        output = "Solver Status:\n"
+        for (k, v) in self.status.items():
+            output = "\n".join((output, "%s = %s" % (k.rjust(25), v)))
+        return output
+
+    # ------------------------------------------------------------------ host <-> device
+    def _push(self, state):
+        """state.q (host) -> HBM; the device copy becomes authoritative."""
+        q = _lib.fortran64(state.q)
+        _lib.check(_lib.lib().pcl_put_q(self._h, _lib.d(q), 0))
+        self._resident = True
+        self._host_stale = False
+        self._state = state
+
+    def _pull(self, state):
+        """HBM -> state.q (host), if the host copy is stale."""
+        if self._resident and self._host_stale:
+            if not (state.q.flags.f_contiguous and state.q.dtype == np.float64 and state.q.flags.writeable):
+                state.q = np.empty(state.q.shape, order='F')
+            _lib.check(_lib.lib().pcl_get_q(self._h, _lib.d(state.q), 0))
+            self._host_stale = False
+
+    # ------------------------------------------------------------------ boundary conditions
+    def allocate_bc_arrays(self, state):
+        r"""qbc/auxbc host arrays with ghost cells (solver.py:297-313).  qbc is only a staging
+        area for Python custom-BC callbacks here; auxbc is filled once and uploaded."""
+        qbc_dim = [n + 2 * self.mbc for n in state.grid.ng]
+        qbc_dim.insert(0, state.meqn)
+        self.qbc = np.zeros(qbc_dim, order='F')
+        if state.maux > 0:
+            auxbc_dim = [n + 2 * self.mbc for n in state.grid.ng]
+            auxbc_dim.insert(0, state.maux)
+            self.auxbc = np.empty(auxbc_dim, order='F')
+            self.apply_aux_bcs(state)
+        else:
+            self.auxbc = None
+
+    def _at_lower(self, dim):
+        return dim.nstart == 0
+
+    def _at_upper(self, dim):
+        return dim.nend == dim.n
+
+    def apply_q_bcs(self, state):
+        r"""Fill the ghost cells of the resident q (solver.py:315-381), same order: per
+        dimension, lower then upper; only on blocks that touch the physical boundary.  In a
+        decomposed run the halo exchange comes first (petclaw: globalToLocal inside
+        get_qbc_from_q, src/petclaw/state.py:254-262)."""
+        L = _lib.lib()
+        if self._halo_active:
+            _lib.check(L.pcl_halo_exchange(self._h))
+        grid = state.grid
+        for idim, dim in enumerate(grid.dimensions):
+            whole = self._at_lower(dim) and self._at_upper(dim)
+            if self._at_lower(dim):
+                bc = self.bc_lower[idim]
+                if bc == BC.custom:
+                    self._custom_bc(state, dim, idim, 0, self.user_bc_lower)
+                elif bc == BC.periodic:
+                    if whole:
+                        _lib.check(L.pcl_bc(self._h, idim, 0, bc))
+                elif bc in (BC.outflow, BC.reflecting):
+                    _lib.check(L.pcl_bc(self._h, idim, 0, bc))
+                else:
+                    raise NotImplementedError("Boundary condition %s not implemented" % bc)
+            if self._at_upper(dim):
+                bc = self.bc_upper[idim]
+                if bc == BC.custom:
+                    self._custom_bc(state, dim, idim, 1, self.user_bc_upper)
+                elif bc == BC.periodic:
+                    if whole:
+                        _lib.check(L.pcl_bc(self._h, idim, 1, bc))
+                elif bc in (BC.outflow, BC.reflecting):
+                    _lib.check(L.pcl_bc(self._h, idim, 1, bc))
+                else:
+                    raise NotImplementedError("Boundary condition %s not implemented" % bc)
+
+    def _custom_bc(self, state, dim, idim, side, fn):
+        if fn is None:
+            raise Exception("Custom BC requested but user_bc_%s is not set" % ("lower", "upper")[side])
+        if isinstance(fn, DeviceBC):
+            fn.apply(self, idim, side)
+            return
+        # Plain Python callback (state,dim,t,qbc,mbc): give it the reference's full qbc array
+        # (solver.py:404-405), then send back only the ghost layers of this side.
+        L = _lib.lib()
+        _lib.check(L.pcl_get_q(self._h, _lib.d(self.qbc), 1))
+        fn(state, dim, state.t, self.qbc, self.mbc)
+        idx = [slice(None)] * self.qbc.ndim
+        idx[idim + 1] = slice(0, self.mbc) if side == 0 else slice(self.qbc.shape[idim + 1] - self.mbc, None)
+        strip = np.asfortranarray(self.qbc[tuple(idx)])
+        _lib.check(L.pcl_put_strip(self._h, idim, side, self.mbc, _lib.d(strip)))
+
+    def apply_aux_bcs(self, state):
+        r"""Host-side aux ghost fill, once at setup (solver.py:456-596)."""
+        self.auxbc = state.get_qbc_from_q(self.mbc, 'aux', self.auxbc)
+        grid = state.grid
+        mbc = self.mbc
+        for idim, dim in enumerate(grid.dimensions):
+            whole = self._at_lower(dim) and self._at_upper(dim)
+            if self._at_lower(dim):
+                bc = self.aux_bc_lower[idim]
+                if bc == BC.custom:
+                    self.user_aux_bc_lower(state, dim, state.t, self.auxbc, mbc)
+                elif bc == BC.periodic and not whole:
+                    pass
+                else:
+                    a = np.rollaxis(self.auxbc, idim + 1, 1)
+                    if bc == BC.outflow:
+                        for i in range(mbc):
+                            a[:, i, ...] = a[:, mbc, ...]
+                    elif bc == BC.periodic:
+                        a[:, :mbc, ...] = a[:, -2 * mbc:-mbc, ...]
+                    elif bc == BC.reflecting:
+                        for i in range(mbc):
+                            a[:, i, ...] = a[:, 2 * mbc - 1 - i, ...]
+                    elif bc is None:
+                        raise Exception("One or more of the aux boundary conditions aux_bc_upper has not been specified.")
+                    else:
+                        raise NotImplementedError("Boundary condition %s not implemented" % bc)
+            if self._at_upper(dim):
+                bc = self.aux_bc_upper[idim]
+                if bc == BC.custom:
+                    self.user_aux_bc_upper(state, dim, state.t, self.auxbc, mbc)
+                elif bc == BC.periodic and not whole:
+                    pass
+                else:
+                    a = np.rollaxis(self.auxbc, idim + 1, 1)
+                    if bc == BC.outflow:
+                        for i in range(mbc):
+                            a[:, -i - 1, ...] = a[:, -mbc - 1, ...]
+                    elif bc == BC.periodic:
+                        a[:, -mbc:, ...] = a[:, mbc:2 * mbc, ...]
+                    elif bc == BC.reflecting:
+                        for i in range(mbc):
+                            a[:, -i - 1, ...] = a[:, -2 * mbc + i, ...]
+                    elif bc is None:
+                        raise Exception("One or more of the aux boundary conditions aux_bc_lower has not been specified.")
+                    else:
+                        raise NotImplementedError("Boundary condition %s not implemented" % bc)
+
+    # ------------------------------------------------------------------ multi-GPU glue
+    _halo_active = False
+
+    def _setup_halo(self, state):
+        """Join the RCCL communicator if the state's grid is decomposed over several GPUs."""
+        dec = state.decomp
+        if dec is None:
+            self._halo_active = False
+            return
+        L = _lib.lib()
+        import ctypes as C
+        uid = C.create_string_buffer(128)
+        if parallel.rank() == 0:
+            _lib.check(L.pcl_comm_unique_id(uid))
+        raw = parallel.broadcast_bytes(uid.raw if parallel.rank() == 0 else None, src=0)
+        uid = C.create_string_buffer(raw, 128)
+        periodic = [self.bc_lower[k] == BC.periodic for k in range(state.grid.ndim)]
+        nbr = np.array(dec.neighbors(periodic), dtype=np.int32)
+        _lib.check(L.pcl_comm_init(self._h, parallel.world_size(), parallel.rank(), uid, _lib.i(nbr)))
+        self._halo_active = True
+        import ctypes
+
+        def reduce_max(v):
+            box = ctypes.c_double(v)
+            _lib.check(L.pcl_allreduce_max(self._h, ctypes.cast(ctypes.byref(box), _lib.dp)))
+            return box.value
+        self.cfl._reduce = reduce_max
+
+    # ------------------------------------------------------------------ evolution
+    def evolve_to_time(self, solution, tend=None):
+        r"""Evolve solution from solution.t to tend (one step if tend is None); returns the
+        status dict.  Line-for-line semantics of solver.py:602-717."""
+        if self._h is None:
+            raise Exception("solver.setup(solution) must be called before evolve_to_time")
+        take_one_step = tend is None
+        retake_step = False
+        tstart = solution.t
+
+        self.status['cflmax'] = self.cfl.get_cached_max()
+        self.status['dtmin'] = self.dt
+        self.status['dtmax'] = self.dt
+        self.status['numsteps'] = 0
+
+        if not self.dt_variable:
+            if take_one_step:
+                self.max_steps = 1
+            else:
+                self.max_steps = int((tend - tstart + 1e-10) / self.dt)
+                if abs(self.max_steps * self.dt - (tend - tstart)) > 1e-5 * (tend - tstart):
+                    raise Exception('dt does not divide (tend-tstart) and dt is fixed!')
+        if self.dt_variable == 1 and self.cfl_desired > self.cfl_max:
+            raise Exception('Variable time-stepping and desired CFL > maximum CFL')
+        if (not take_one_step) and tend <= tstart:
+            self.logger.info("Already at or beyond end time: no evolution required.")
+            self.max_steps = 0
+
+        state = solution.state
+        self._push(state)
+        try:
+            for n in range(self.max_steps):
+                state = solution.state
+                if (not take_one_step) and solution.t + self.dt > tend and tstart < tend:
+                    self.dt = tend - solution.t
+
+                if self.dt_variable:
+                    self._backup(state)          # q_backup = state.q.copy('F')
+                    told = solution.t
+                retake_step = False
+
+                self.step(solution)
+
+                cfl = self.cfl.get_cached_max()
+                if cfl <= self.cfl_max:
+                    self.status['cflmax'] = max(cfl, self.status['cflmax'])
+                    if self.dt_variable == True:
+                        solution.t += self.dt
+                    else:
+                        solution.t = tstart + (n + 1) * self.dt
+                    self.logger.debug("Step %i  CFL = %f   dt = %f   t = %f" % (n, cfl, self.dt, solution.t))
+                    self.write_gauge_values(solution)
+                    self.status['numsteps'] += 1
+                    if take_one_step or solution.t >= tend:
+                        break
+                else:
+                    self.logger.debug("Rejecting time step, CFL number too large")
+                    if self.dt_variable:
+                        self._restore(state)     # state.q = q_backup
+                        solution.t = told
+                        retake_step = True
+                    else:
+                        self.status['cflmax'] = max(cfl, self.status['cflmax'])
+                        raise Exception('CFL too large, giving up!')
+
+                if self.dt_variable:
+                    if cfl > 0.0:
+                        self.dt = min(self.dt_max, self.dt * self.cfl_desired / cfl)
+                        self.status['dtmin'] = min(self.dt, self.status['dtmin'])
+                        self.status['dtmax'] = max(self.dt, self.status['dtmax'])
+                    else:
+                        self.dt = self.dt_max
+        finally:
+            self._pull(solution.state)
+            self._resident = False
+
+        if self.dt_variable and (not take_one_step) and solution.t < tend \
+                and self.status['numsteps'] == self.max_steps:
+            raise Exception("Maximum number of timesteps have been taken")
+        return self.status
+
+    def step(self, solution):
+        raise NotImplementedError("No stepping routine has been defined!")
+
+    # backup/restore of the resident state; subclasses pick the cheap form when legal
+    def _backup(self, state):
+        _lib.check(_lib.lib().pcl_backup(self._h))
+
+    def _restore(self, state):
+        _lib.check(_lib.lib().pcl_restore(self._h))
+        self._host_stale = True
+
+    # ------------------------------------------------------------------ gauges
+    def write_gauge_values(self, solution):
+        r"""solver.py:731-741"""
+        gauges = solution.state.grid.gauges
+        if not gauges:
+            return
+        self._pull(solution.state)
+        for i, gauge in enumerate(gauges):
+            x = gauge[0]
+            y = gauge[1]
+            aux = solution.state.aux[:, x, y]
+            q = solution.state.q[:, x, y]
+            p = self.compute_gauge_values(q, aux)
+            t = solution.t
+            solution.state.grid.gauge_files[i].write(str(t) + ' ' + ' '.join(str(j) for j in p) + '\n')
