@@ -1,0 +1,244 @@
+"""
+The reference's regression problems written against the pyclaw_amd surface, the way the
+reference scripts are written against pyclaw (test/euler/2d/shockbubble.py,
+test/acoustics/2d/homogeneous/acoustics.py, test/acoustics/1d/homogeneous/acoustics.py,
+apps/advection/1d/constant/advection.py).  Shared by the GPU tests, smoke() and bench.py.
+"""
+import numpy as np
+
+gamma = 1.4
+gamma1 = gamma - 1.
+
+
+def shock_state(pinf=5.):
+    rinf = (gamma1 + pinf * (gamma + 1.)) / ((gamma + 1.) + gamma1 * pinf)
+    vinf = 1. / np.sqrt(gamma) * (pinf - 1.) / np.sqrt(0.5 * ((gamma + 1.) / gamma) * pinf + 0.5 * gamma1 / gamma)
+    einf = 0.5 * rinf * vinf ** 2 + pinf / gamma1
+    return rinf, vinf, einf
+
+
+def sb_qinit(state, x0=0.5, y0=0., r0=0.2, rhoin=0.1, pinf=5.):
+    grid = state.grid
+    rhoout = 1.
+    pout = 1.
+    pin = 1.
+    x = grid.x.center
+    y = grid.y.center
+    Y, X = np.meshgrid(y, x)
+    r = np.sqrt((X - x0) ** 2 + (Y - y0) ** 2)
+    state.q[0, :, :] = rhoin * (r <= r0) + rhoout * (r > r0)
+    state.q[1, :, :] = 0.
+    state.q[2, :, :] = 0.
+    state.q[3, :, :] = (pin * (r <= r0) + pout * (r > r0)) / gamma1
+    state.q[4, :, :] = 1. * (r <= r0)
+
+
+def sb_auxinit(state):
+    y = state.grid.y.center
+    for j, ycoord in enumerate(y):
+        state.aux[0, :, j] = ycoord
+
+
+def shockbc(state, dim, t, qbc, mbc):
+    if dim.nstart == 0:
+        rinf, vinf, einf = shock_state()
+        for i in range(mbc):
+            qbc[0, i, ...] = rinf
+            qbc[1, i, ...] = rinf * vinf
+            qbc[2, i, ...] = 0.
+            qbc[3, i, ...] = einf
+            qbc[4, i, ...] = 0.
+
+
+def euler_rad_src(solver, state, dt):
+    dt2 = dt / 2.
+    ndim = 2
+    aux = state.aux
+    q = state.q
+    rad = aux[0, :, :]
+    rho = q[0, :, :]
+    u = q[1, :, :] / rho
+    v = q[2, :, :] / rho
+    press = gamma1 * (q[3, :, :] - 0.5 * rho * (u ** 2 + v ** 2))
+    qstar = np.empty(q.shape)
+    qstar[0, :, :] = q[0, :, :] - dt2 * (ndim - 1) / rad * q[2, :, :]
+    qstar[1, :, :] = q[1, :, :] - dt2 * (ndim - 1) / rad * rho * u * v
+    qstar[2, :, :] = q[2, :, :] - dt2 * (ndim - 1) / rad * rho * v * v
+    qstar[3, :, :] = q[3, :, :] - dt2 * (ndim - 1) / rad * v * (q[3, :, :] + press)
+    rho = qstar[0, :, :]
+    u = qstar[1, :, :] / rho
+    v = qstar[2, :, :] / rho
+    press = gamma1 * (qstar[3, :, :] - 0.5 * rho * (u ** 2 + v ** 2))
+    q[0, :, :] = q[0, :, :] - dt * (ndim - 1) / rad * qstar[2, :, :]
+    q[1, :, :] = q[1, :, :] - dt * (ndim - 1) / rad * rho * u * v
+    q[2, :, :] = q[2, :, :] - dt * (ndim - 1) / rad * rho * v * v
+    q[3, :, :] = q[3, :, :] - dt * (ndim - 1) / rad * v * (qstar[3, :, :] + press)
+
+
+def shockbubble(pyclaw, mx=160, my=40, tfinal=0.2, device_callbacks=False, with_src=True,
+                dim_split=True, order_trans=2, dt_initial=0.005, nout=1, run=True):
+    """test/euler/2d/shockbubble.py:97-166.  device_callbacks=True swaps the Python
+    custom-BC / source callbacks for the built-in device versions (same arithmetic)."""
+    x = pyclaw.Dimension('x', 0.0, 2.0, mx)
+    y = pyclaw.Dimension('y', 0.0, 0.5, my)
+    grid = pyclaw.Grid([x, y])
+    meqn = 5
+    maux = 1
+    state = pyclaw.State(grid, meqn, maux)
+    state.aux_global['gamma'] = gamma
+    state.aux_global['gamma1'] = gamma1
+    sb_qinit(state)
+    sb_auxinit(state)
+    initial_solution = pyclaw.Solution(state)
+
+    solver = pyclaw.ClawSolver2D()
+    solver.rp = pyclaw.riemann.rp_euler_5wave_2d
+    solver.cfl_max = 0.5
+    solver.cfl_desired = 0.45
+    solver.mwaves = 5
+    solver.limiters = [4, 4, 4, 4, 2]
+    solver.dt_initial = dt_initial
+    solver.dim_split = dim_split
+    solver.order_trans = order_trans
+    if device_callbacks:
+        rinf, vinf, einf = shock_state()
+        solver.user_bc_lower = pyclaw.ConstantStateBC([rinf, rinf * vinf, 0., einf, 0.])
+        solver.step_src = pyclaw.EulerRadialSource(gamma1, 2) if with_src else None
+    else:
+        solver.user_bc_lower = shockbc
+        solver.step_src = euler_rad_src if with_src else None
+    solver.src_split = 1
+    solver.bc_lower[0] = pyclaw.BC.custom
+    solver.bc_upper[0] = pyclaw.BC.outflow
+    solver.bc_lower[1] = pyclaw.BC.reflecting
+    solver.bc_upper[1] = pyclaw.BC.outflow
+    solver.aux_bc_lower[0] = pyclaw.BC.outflow
+    solver.aux_bc_upper[0] = pyclaw.BC.outflow
+    solver.aux_bc_lower[1] = pyclaw.BC.outflow
+    solver.aux_bc_upper[1] = pyclaw.BC.outflow
+
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.tfinal = tfinal
+    claw.solution = initial_solution
+    claw.solver = solver
+    claw.nout = nout
+    if not run:
+        return claw
+    claw.run()
+    return claw
+
+
+def ac2d_qinit(state, width=0.2):
+    grid = state.grid
+    x = grid.x.center
+    y = grid.y.center
+    Y, X = np.meshgrid(y, x)
+    r = np.sqrt(X ** 2 + Y ** 2)
+    state.q[0, :, :] = (np.abs(r - 0.5) <= width) * (1. + np.cos(np.pi * (r - 0.5) / width))
+    state.q[1, :, :] = 0.
+    state.q[2, :, :] = 0.
+
+
+def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=True):
+    """test/acoustics/2d/homogeneous/acoustics.py:19-86 (classic)."""
+    solver = pyclaw.ClawSolver2D()
+    solver.rp = pyclaw.riemann.rp_acoustics_2d
+    solver.cfl_max = 0.5
+    solver.cfl_desired = 0.45
+    solver.mwaves = 2
+    solver.dim_split = dim_split
+    solver.limiters = [4] * solver.mwaves
+    solver.bc_lower[0] = pyclaw.BC.outflow
+    solver.bc_upper[0] = pyclaw.BC.outflow
+    solver.bc_lower[1] = pyclaw.BC.outflow
+    solver.bc_upper[1] = pyclaw.BC.outflow
+    x = pyclaw.Dimension('x', -1.0, 1.0, mx)
+    y = pyclaw.Dimension('y', -1.0, 1.0, my)
+    grid = pyclaw.Grid([x, y])
+    state = pyclaw.State(grid, 3)
+    rho = 1.0
+    bulk = 4.0
+    cc = np.sqrt(bulk / rho)
+    zz = rho * cc
+    state.aux_global['rho'] = rho
+    state.aux_global['bulk'] = bulk
+    state.aux_global['zz'] = zz
+    state.aux_global['cc'] = cc
+    ac2d_qinit(state)
+    initial_solution = pyclaw.Solution(state)
+    solver.dt_initial = np.min(grid.d) / state.aux_global['cc'] * solver.cfl_desired
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.tfinal = tfinal
+    claw.solution = initial_solution
+    claw.solver = solver
+    claw.nout = nout
+    if not run:
+        return claw
+    claw.run()
+    return claw
+
+
+def acoustics1D(pyclaw, mx=100):
+    """test/acoustics/1d/homogeneous/acoustics.py (classic): returns the one-period L1 error."""
+    solver = pyclaw.ClawSolver1D()
+    solver.rp = pyclaw.riemann.rp_acoustics_1d
+    x = pyclaw.Dimension('x', 0.0, 1.0, mx)
+    grid = pyclaw.Grid(x)
+    state = pyclaw.State(grid, 2)
+    rho = 1.0
+    bulk = 1.0
+    state.aux_global['rho'] = rho
+    state.aux_global['bulk'] = bulk
+    state.aux_global['zz'] = np.sqrt(rho * bulk)
+    state.aux_global['cc'] = np.sqrt(rho / bulk)
+    xc = grid.x.center
+    beta = 100
+    gam = 0
+    x0 = 0.75
+    state.q[0, :] = np.exp(-beta * (xc - x0) ** 2) * np.cos(gam * (xc - x0))
+    state.q[1, :] = 0.
+    init_solution = pyclaw.Solution(state)
+    solver.mwaves = 2
+    solver.limiters = [4] * solver.mwaves
+    solver.dt_initial = grid.d[0] / state.aux_global['cc'] * 0.1
+    solver.bc_lower[0] = pyclaw.BC.periodic
+    solver.bc_upper[0] = pyclaw.BC.periodic
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.nout = 5
+    claw.tfinal = 1.0
+    claw.solution = init_solution
+    claw.solver = solver
+    claw.run()
+    q0 = claw.frames[0].state.q.reshape([-1])
+    qfinal = claw.frames[claw.nout].state.q.reshape([-1])
+    dx = claw.frames[0].grid.d[0]
+    return dx * np.sum(np.abs(qfinal - q0)), claw
+
+
+def advection1D(pyclaw, mx=1000, tfinal=1.0, nout=10):
+    """apps/advection/1d/constant/advection.py:3-44 at the C1 size (1000 cells)."""
+    solver = pyclaw.ClawSolver1D()
+    solver.rp = pyclaw.riemann.rp_advection_1d
+    solver.mwaves = 1
+    solver.bc_lower[0] = 2
+    solver.bc_upper[0] = 2
+    x = pyclaw.Dimension('x', 0.0, 1.0, mx)
+    grid = pyclaw.Grid(x)
+    state = pyclaw.State(grid, 1)
+    state.aux_global['u'] = 1.
+    xc = grid.x.center
+    beta = 100
+    gam = 0
+    x0 = 0.75
+    state.q[0, :] = np.exp(-beta * (xc - x0) ** 2) * np.cos(gam * (xc - x0))
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.solution = pyclaw.Solution(state)
+    claw.solver = solver
+    claw.tfinal = tfinal
+    claw.nout = nout
+    claw.run()
+    return claw

@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark: Mcell.steps/s of the classic dimension-split step on the
+2-D Euler shock-bubble problem (BASELINE.json configs[2]: 4096 x 4096 cells on one MI355X).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--nx 4096 --ny 4096]
+
+One "step" = one accepted pass of the hot path on the block resident in HBM: ghost-cell
+fill (+ halo exchange when N > 1), x sweep, y sweep, device CFL reduction, the 8-byte CFL
+read-back and the host's accept/retake + dt update -- i.e. solver.evolve_to_time(solution)
+taking one step, exactly what the reference's Controller drives.  The source term is off
+(the "classic step" figure of SURVEY 8d); inputs are synthetic (the shock-bubble initial
+condition evaluated on the benchmark grid).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns
+a 4096 x 4096 block of a (4096*px) x (4096*py) grid, halo exchange over RCCL, CFL all-reduce.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+"roofline" (dominant sweep kernel, HIP-event timed inside the timed region) and
+"cpu_baseline" (the reference Fortran / the C port of it timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_CELL_SWEEP = 2 * 5 * 8   # read + write of q (5 doubles) per directional pass
+
+
+def build(nx_global, ny_global):
+    import pyclaw_amd as pyclaw
+    from apps import problems
+    # dt_initial scaled with dx like the reference test (0.005 at dx=1/80) -> first CFL ~ 0.4-0.5
+    dt0 = 0.005 * (2.0 / nx_global) / (2.0 / 160.0)
+    claw = problems.shockbubble(pyclaw, mx=nx_global, my=ny_global, device_callbacks=True,
+                                with_src=False, dt_initial=dt0, run=False)
+    return claw
+
+
+def cpu_baseline(nx, ny, max_seconds=30.0):
+    """Time the reference's CPU path on ONE core on a bounded sample of the same workload:
+    whole dim-split steps (x then y sweep) of the same Euler state on an nx x (rows) slab.
+    kind 'reference' = oracle/_ref (the reference Fortran itself, flang-built); 'port' = the
+    C restatement.  The slab height is chosen so the sample takes ~10-20 s."""
+    from oracle import oracle as O
+    from oracle import driver as D
+    if O.RefEuler2D.available():
+        be, kind = O.RefEuler2D(), "reference"
+    else:
+        be, kind = O.COracle(), "port"
+    # ~1.3 Mcell.steps/s/core was measured at survey time: 16 M cells ~ 13 s
+    sy = max(8, min(ny, int(16.0e6 / nx)))
+    p = D.shockbubble_problem(mx=nx, my=sy, with_src=False)
+    p.d = (2.0 / nx, 0.5 / ny)
+    p.dt_initial = 0.005 * (2.0 / nx) / (2.0 / 160.0)
+    D.setup(p)
+    p.dt = p.dt_initial
+    t0 = time.perf_counter()
+    nsteps = 0
+    while True:
+        D.step_hyperbolic(p, be)
+        nsteps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or nsteps >= 3 or el * (nsteps + 1) / nsteps > max_seconds:
+            break
+    el = time.perf_counter() - t0
+    return {"value": nx * sy * nsteps / el / 1e6, "unit": "Mcell*steps/s", "cores": 1, "kind": kind,
+            "sample": "%d dim-split steps of the same shock-bubble state on a %dx%d slab (%.1f s)"
+                      % (nsteps, nx, sy, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nx", type=int, default=4096, help="cells per GPU block in x")
+    ap.add_argument("--ny", type=int, default=4096, help="cells per GPU block in y")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from pyclaw_amd import parallel, _lib
+    parallel.init()
+    rank, size = parallel.rank(), parallel.world_size()
+    if size != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)\n"
+                             % (args.gpus, size))
+        sys.exit(2)
+
+    dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
+    nxg, nyg = args.nx * dims[0], args.ny * dims[1]
+    claw = build(nxg, nyg)
+    solver, solution = claw.solver, claw.solution
+    solver.setup(solution)
+    solver.dt = solver.dt_initial
+    L = _lib.lib()
+    h = solver._h
+
+    solver.begin_resident(solution)
+    for _ in range(args.warmup):
+        solver.evolve_to_time(solution)
+
+    # ---- timed region: exactly K accepted steps --------------------------------------
+    _lib.check(L.pcl_kernel_timing(h, 1))
+    parallel.barrier()
+    _lib.check(L.pcl_sync(h))
+    nrej0 = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.evolve_to_time(solution)
+    _lib.check(L.pcl_sync(h))
+    parallel.barrier()
+    t1 = time.perf_counter()
+    elapsed = parallel.allreduce_max_host(t1 - t0)
+
+    ms = np.zeros(2)
+    nl = np.zeros(2, dtype=np.int64)
+    import ctypes
+    _lib.check(L.pcl_kernel_timing_read(h, _lib.d(ms), nl.ctypes.data_as(ctypes.POINTER(ctypes.c_long))))
+    _lib.check(L.pcl_kernel_timing(h, 0))
+    solver.end_resident(solution)
+    q = solution.state.q
+    finite = bool(np.isfinite(q).all())
+    solver.teardown()
+
+    cells_total = float(nxg) * float(nyg)
+    value = cells_total * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        names = ["sweep_x_kernel<Euler5>", "sweep_y_kernel<Euler5>"]
+        avg = [ms[k] / max(1, nl[k]) for k in range(2)]
+        dom = int(np.argmax(avg))
+        bytes_launch = BYTES_PER_CELL_SWEEP * float(args.nx) * float(args.ny)
+        achieved = bytes_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
+        out = {
+            "metric": "Mcell*steps/s, 2-D Euler classic dim-split step (+ achieved HBM GB/s in roofline)",
+            "value": value, "unit": "Mcell*steps/s", "n_gpus": size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "apps/euler 2D shock-bubble, %dx%d cells per GPU, classic dim-split, "
+                                   "mthlim=[4,4,4,4,2], order 2, source off" % (args.nx, args.ny),
+                       "global_grid": [nxg, nyg], "proc_grid": dims, "math": "exact (no FMA, IEEE div/sqrt)",
+                       "launches": {names[0]: int(nl[0]), names[1]: int(nl[1])},
+                       "steps_incl_rejected": int(nl[0]), "result_finite": finite},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_ms": {names[0]: avg[0], names[1]: avg[1]},
+                         "algorithmic_bytes_per_launch": bytes_launch},
+        }
+        if size == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.nx, args.ny)
+            except Exception as e:      # the oracle is optional infrastructure, never the product
+                out["cpu_baseline"] = {"value": None, "unit": "Mcell*steps/s", "cores": 1, "kind": "port",
+                                       "sample": "failed: %s" % e}
+        print(json.dumps(out))
+    parallel.shutdown()
+
+
+if __name__ == "__main__":
+    main()

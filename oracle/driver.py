@@ -103,7 +103,9 @@ class Problem:
         self.ndim = self.q.ndim - 1
         self.t = 0.0
         self.dt = self.dt_initial
-        self.cfl = self.cfl_desired
+        # solver.py:172: CFL(_default_attr_values['cfl_desired']) -- the CLASS default (0.9 for
+        # ClawSolver, clawpack.py:108), not the user's cfl_desired; it seeds status['cflmax'].
+        self.cfl = 0.9
         self.nrejected = 0
         self.dt_history = []
 

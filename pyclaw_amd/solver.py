@@ -86,6 +86,7 @@ class Solver(object):
         # device handle (libpyclaw_amd) and bookkeeping
         self._h = None
         self._resident = False       # True while the HBM copy is the authoritative q
+        self._pinned = False         # begin_resident()/end_resident(): keep q in HBM across calls
         self._host_stale = False
         self._state = None
 
@@ -319,7 +320,8 @@ class Solver(object):
             self.max_steps = 0
 
         state = solution.state
-        self._push(state)
+        if not self._pinned:
+            self._push(state)
         try:
             for n in range(self.max_steps):
                 state = solution.state
@@ -363,8 +365,9 @@ class Solver(object):
                     else:
                         self.dt = self.dt_max
         finally:
-            self._pull(solution.state)
-            self._resident = False
+            if not self._pinned:
+                self._pull(solution.state)
+                self._resident = False
 
         if self.dt_variable and (not take_one_step) and solution.t < tend \
                 and self.status['numsteps'] == self.max_steps:
@@ -373,6 +376,19 @@ class Solver(object):
 
     def step(self, solution):
         raise NotImplementedError("No stepping routine has been defined!")
+
+    # Extension of the reference surface: keep q resident in HBM across several
+    # evolve_to_time calls (the reference's state.q is host memory, so every call would
+    # otherwise upload at entry and download at exit).  state.q on the host is stale in
+    # between; end_resident() refreshes it.
+    def begin_resident(self, solution):
+        self._push(solution.state)
+        self._pinned = True
+
+    def end_resident(self, solution):
+        self._pull(solution.state)
+        self._pinned = False
+        self._resident = False
 
     # backup/restore of the resident state; subclasses pick the cheap form when legal
     def _backup(self, state):
