@@ -178,7 +178,7 @@ int pcl_allreduce_max(pcl_solver *s, double *value);
 
 /* ---- debug / self-test --------------------------------------------------------------- */
 /* Runs the wavefront neighbour-shift primitive on 64 values: left[l]=in[l-1],
- * right[l]=in[l+1] (end lanes keep their own value). */
+ * right[l]=in[l+1] (the end lane without a source reads 0). */
 int pcl_debug_wave_shift(const double *in64, double *left64, double *right64);
 
 #ifdef __cplusplus

@@ -44,16 +44,19 @@ struct SweepArgs {
 };
 
 // ---- wavefront neighbour shifts ------------------------------------------------------
-__device__ __forceinline__ double from_left(double x) {  // lane l <- lane l-1 (lane 0 keeps x)
+// bound_ctrl:0 => the lane without a source (lane 0 / lane 63) reads 0 and no "old" value has
+// to be kept alive, so the shift is a single v_mov_b32_dpp per dword.  Those end lanes
+// never feed a stored result (only lanes 2..61 are written).
+__device__ __forceinline__ double from_left(double x) {  // lane l <- lane l-1 (lane 0 gets 0)
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double from_right(double x) {  // lane l <- lane l+1 (lane 63 keeps x)
+__device__ __forceinline__ double from_right(double x) {  // lane l <- lane l+1 (lane 63 gets 0)
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);  // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <class T> __device__ __forceinline__ T struct_from_left(const T &t) {
@@ -127,14 +130,17 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
         for (int mw = 0; mw < MWAVES; mw++) {
             const int lim = a.mthlim[mw];
             if (lim == 0) continue;
+            // (the Fortran starts both sums at 0.d0; 0 + x == x up to the sign of a zero)
             double wn = 0.0, dl = 0.0;
+            bool first = true;
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
                 if (!RP::template nz<IXY>(mw, m)) continue;
                 const double w = wave[mw][m];
                 const double wl = from_left(w);
-                wn = wn + w * w;
-                dl = dl + wl * w;
+                wn = first ? w * w : wn + w * w;
+                dl = first ? wl * w : dl + wl * w;
+                first = false;
             }
             const double dr = from_right(dl);
             if (wn != 0.0) {
@@ -160,9 +166,13 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
 #pragma unroll
         for (int m = 0; m < MEQN; m++) {
             double c = 0.0;
+            bool first = true;
 #pragma unroll
             for (int mw = 0; mw < MWAVES; mw++)
-                if (RP::template nz<IXY>(mw, m)) c = c + coef[mw] * wave[mw][m];
+                if (RP::template nz<IXY>(mw, m)) {
+                    c = first ? coef[mw] * wave[mw][m] : c + coef[mw] * wave[mw][m];
+                    first = false;
+                }
             fadd[m] = DIM1 ? c : 0.5 * c;
         }
     }
@@ -177,7 +187,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
             t = t - dtdx_c * amdq_r;
             qn[m] = (a.order != 1) ? t - dtdx_c * (fadd_r - fadd[m]) : t;
         } else {
-            double qadd = 0.0 - dtdx_c * apdq[m];
+            double qadd = -(dtdx_c * apdq[m]);  // 0.d0 - dtdx1d(i)*apdq(m,i)
             qadd = qadd - dtdx_c * amdq_r;
             if (CAPA)
                 qn[m] = q[m] + qadd - a.dtd * (fadd_r - fadd[m]) / capa;
@@ -191,13 +201,12 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
 // grid: one wavefront per (row, strip); 4 wavefronts per workgroup.
 // Covers step2ds ids=1 (all rows incl. ghost rows) and the 1-D step (J == 1).
 template <class RP, bool CAPA, bool FWAVE, bool DIM1>
-__global__ __launch_bounds__(256) void sweep_x_kernel(SweepArgs a, int nstrips, long nwork) {
+__global__ __launch_bounds__(256) void sweep_x_kernel(SweepArgs a, int nstrips) {
     constexpr int MEQN = RP::MEQN;
     const int lane = threadIdx.x & (WAVE - 1);
-    const long wid = (long)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
-    if (wid >= nwork) return;  // whole wavefront leaves together
-    const int row = (int)(wid / nstrips);
-    const int strip = (int)(wid % nstrips);
+    const int row = blockIdx.y;
+    const int strip = blockIdx.x * (256 / WAVE) + (threadIdx.x / WAVE);
+    if (strip >= nstrips) return;  // whole wavefront leaves together
     const int c0 = a.mbc - HALO + strip * STRIP;
     const int c = c0 + lane;
     const int cc = c < a.I ? c : a.I - 1;  // clamp: lanes past the row end recompute the last cell

@@ -177,17 +177,17 @@ SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, dou
 
 template <class RP, bool DIM1> int launch_x(pcl_solver *s, const SweepArgs &a) {
     const int nstrips = (a.mx + STRIP - 1) / STRIP;
-    const long nwork = (long)nstrips * a.J;
     const int wpb = 4;
-    const unsigned grid = (unsigned)((nwork + wpb - 1) / wpb);
+    if (a.J > 65535) return fail(PCL_EINVAL, "more than 65535 rows");
+    const dim3 grid((unsigned)((nstrips + wpb - 1) / wpb), (unsigned)a.J);
     const bool capa = a.mcapa > 0;
     if (s->cfg.fwave) return fail(PCL_EINVAL, "fwave: no f-wave Riemann solver is built in yet");
     if (capa)
-        hipLaunchKernelGGL((sweep_x_kernel<RP, true, false, DIM1>), dim3(grid), dim3(256), 0, s->stream,
-                           a, nstrips, nwork);
+        hipLaunchKernelGGL((sweep_x_kernel<RP, true, false, DIM1>), grid, dim3(256), 0, s->stream,
+                           a, nstrips);
     else
-        hipLaunchKernelGGL((sweep_x_kernel<RP, false, false, DIM1>), dim3(grid), dim3(256), 0,
-                           s->stream, a, nstrips, nwork);
+        hipLaunchKernelGGL((sweep_x_kernel<RP, false, false, DIM1>), grid, dim3(256), 0,
+                           s->stream, a, nstrips);
     HIP_TRY(hipGetLastError());
     return PCL_OK;
 }

@@ -23,8 +23,55 @@ struct RpParams {
     double v[8];
 };
 
-__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
-__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+// dmax1/dmin1 of the Fortran.  v_max_f64/v_min_f64 are one instruction; the compare+select
+// form costs a v_cmp, a 2-wait-state VCC hazard and two v_cndmask.  They differ from the
+// Fortran intrinsics only for NaN operands and in the sign of a zero result.
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
+
+// ---- square root ---------------------------------------------------------------------------
+// Same Goldschmidt/Newton sequence hipcc emits for an IEEE f64 sqrt (v_rsq_f64 seed, one
+// coupled g/h step, two fma residual corrections => correctly rounded), minus the 2^256 input
+// pre-scaling it adds for arguments below 2^-767, which no density/sound-speed ever is.
+// 0, +inf (and NaN / negative => NaN) behave like sqrt().
+__device__ __forceinline__ double dsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;  // +-0, +inf pass through
+}
+
+// ---- division by a shared denominator ----------------------------------------------------
+// The reference divides several numerators by the same value (q/rho, q/sqrt(rho), ./rhsq2).
+// hipcc expands every IEEE f64 division into: 2 v_div_scale, v_rcp_f64, 4 fma (Newton on the
+// reciprocal), mul, fma, v_div_fmas, v_div_fixup.  The reciprocal part depends on the
+// denominator only, so it is computed once; each quotient then costs mul + 2 fma + fixup.
+// The quotient is the same correctly rounded value (Markstein: q' = fma(fma(-d,q,n), r, q)
+// with r within 1 ulp of 1/d) as long as no operand needs v_div_scale's range scaling,
+// i.e. exponents stay away from the ends of the double range (|x| in 2^-700 .. 2^700);
+// zero / inf / NaN operands are still handled by v_div_fixup exactly like the full form.
+struct Recip {
+    double d, r;
+    __device__ __forceinline__ explicit Recip(double den) : d(den) {
+        double y = __builtin_amdgcn_rcp(den);
+        double e = __builtin_fma(-den, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-den, y, 1.0);
+        r = __builtin_fma(y, e, y);
+    }
+    __device__ __forceinline__ double div(double n) const {
+        const double q = n * r;
+        const double e = __builtin_fma(-d, q, n);
+        return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), d, n);
+    }
+};
 
 // ------------------------------------------------------------------------------------
 // 1-D advection, q_t + u q_x = 0  (third-party rp1_advection.f, restated)
@@ -144,25 +191,26 @@ struct Euler5 {
         const double gamma = par.v[0], gamma1 = par.v[1];
         Cell c;
         for (int m = 0; m < 5; m++) c.q[m] = q[m];
-        c.rs = sqrt(q[0]);
-        c.p = gamma1 * (q[3] - 0.5 * (q[1] * q[1] + q[2] * q[2]) / q[0]);
-        c.qu_rs = q[mu] / c.rs;
-        c.qv_rs = q[mv] / c.rs;
-        c.h_rs = (q[3] + c.p) / c.rs;
-        c.c = sqrt(gamma * c.p / q[0]);
-        c.un = q[mu] / q[0];
+        c.rs = dsqrt(q[0]);
+        const Recip by_rho(q[0]), by_rs(c.rs);
+        c.p = gamma1 * (q[3] - by_rho.div(0.5 * (q[1] * q[1] + q[2] * q[2])));
+        c.qu_rs = by_rs.div(q[mu]);
+        c.qv_rs = by_rs.div(q[mv]);
+        c.h_rs = by_rs.div(q[3] + c.p);
+        c.c = dsqrt(by_rho.div(gamma * c.p));
+        c.un = by_rho.div(q[mu]);
         return c;
     }
     struct Roe { double u, v, enth, a, g1a2, euv, u2v2; };
     __device__ static __forceinline__ Roe roe(const Cell &L, const Cell &R, double gamma1) {
         Roe r;
-        const double rhsq2 = L.rs + R.rs;
-        r.u = (L.qu_rs + R.qu_rs) / rhsq2;
-        r.v = (L.qv_rs + R.qv_rs) / rhsq2;
-        r.enth = (L.h_rs + R.h_rs) / rhsq2;
+        const Recip by_rhsq2(L.rs + R.rs);
+        r.u = by_rhsq2.div(L.qu_rs + R.qu_rs);
+        r.v = by_rhsq2.div(L.qv_rs + R.qv_rs);
+        r.enth = by_rhsq2.div(L.h_rs + R.h_rs);
         r.u2v2 = r.u * r.u + r.v * r.v;
         const double a2 = gamma1 * (r.enth - .5 * r.u2v2);
-        r.a = sqrt(a2);
+        r.a = dsqrt(a2);
         r.g1a2 = gamma1 / a2;
         r.euv = r.enth - r.u2v2;
         return r;
@@ -203,9 +251,10 @@ struct Euler5 {
             const double rhou1 = L.q[mu] + wave[0][mu];
             const double rhov1 = L.q[mv] + wave[0][mv];
             const double en1 = L.q[3] + wave[0][3];
-            const double p1 = gamma1 * (en1 - 0.5 * (rhou1 * rhou1 + rhov1 * rhov1) / rho1);
-            const double c1 = sqrt(gamma * p1 / rho1);
-            const double s1 = rhou1 / rho1 - c1;
+            const Recip by_rho1(rho1);
+            const double p1 = gamma1 * (en1 - by_rho1.div(0.5 * (rhou1 * rhou1 + rhov1 * rhov1)));
+            const double c1 = dsqrt(by_rho1.div(gamma * p1));
+            const double s1 = by_rho1.div(rhou1) - c1;
             double sfract;
             if (s0 < 0.0 && s1 > 0.0)
                 sfract = s0 * (s1 - s[0]) / (s1 - s0);
@@ -226,9 +275,10 @@ struct Euler5 {
             const double rhou2 = R.q[mu] - wave[3][mu];
             const double rhov2 = R.q[mv] - wave[3][mv];
             const double en2 = R.q[3] - wave[3][3];
-            const double p2 = gamma1 * (en2 - 0.5 * (rhou2 * rhou2 + rhov2 * rhov2) / rho2);
-            const double c2 = sqrt(gamma * p2 / rho2);
-            const double s2 = rhou2 / rho2 + c2;
+            const Recip by_rho2(rho2);
+            const double p2 = gamma1 * (en2 - by_rho2.div(0.5 * (rhou2 * rhou2 + rhov2 * rhov2)));
+            const double c2 = dsqrt(by_rho2.div(gamma * p2));
+            const double s2 = by_rho2.div(rhou2) + c2;
             double sfract = 0.0;
             bool add4 = true;
             if (s2 < 0.0 && s3 > 0.0)
@@ -246,8 +296,12 @@ struct Euler5 {
         // apdq = sum_mw s*wave - amdq  (rpn2:291-298), zero wave entries skipped
         for (int m = 0; m < 5; m++) {
             double df = 0.0;
+            bool first = true;
             for (int mw = 0; mw < 5; mw++)
-                if (nz<IXY>(mw, m)) df = df + s[mw] * wave[mw][m];
+                if (nz<IXY>(mw, m)) {
+                    df = first ? s[mw] * wave[mw][m] : df + s[mw] * wave[mw][m];
+                    first = false;
+                }
             apdq[m] = df - amdq[m];
         }
     }
