@@ -76,7 +76,7 @@ def euler_rad_src(solver, state, dt):
 
 
 def shockbubble(pyclaw, mx=160, my=40, tfinal=0.2, device_callbacks=False, with_src=True,
-                dim_split=True, order_trans=2, dt_initial=0.005, nout=1, run=True):
+                dim_split=True, order_trans=2, dt_initial=0.005, nout=1, run=True, math='exact'):
     """test/euler/2d/shockbubble.py:97-166.  device_callbacks=True swaps the Python
     custom-BC / source callbacks for the built-in device versions (same arithmetic)."""
     x = pyclaw.Dimension('x', 0.0, 2.0, mx)
@@ -92,6 +92,7 @@ def shockbubble(pyclaw, mx=160, my=40, tfinal=0.2, device_callbacks=False, with_
     initial_solution = pyclaw.Solution(state)
 
     solver = pyclaw.ClawSolver2D()
+    solver.math = math
     solver.rp = pyclaw.riemann.rp_euler_5wave_2d
     solver.cfl_max = 0.5
     solver.cfl_desired = 0.45
@@ -140,9 +141,10 @@ def ac2d_qinit(state, width=0.2):
     state.q[2, :, :] = 0.
 
 
-def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=True):
+def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=True, math='exact'):
     """test/acoustics/2d/homogeneous/acoustics.py:19-86 (classic)."""
     solver = pyclaw.ClawSolver2D()
+    solver.math = math
     solver.rp = pyclaw.riemann.rp_acoustics_2d
     solver.cfl_max = 0.5
     solver.cfl_desired = 0.45

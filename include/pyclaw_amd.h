@@ -61,6 +61,9 @@ extern "C" {
 /* arithmetic mode */
 #define PCL_MATH_EXACT 0 /* no FMA contraction, IEEE divide/sqrt: bit-identical to the  */
                          /* reference Fortran built without FMA (the parity mode)        */
+#define PCL_MATH_FAST 1  /* FMA contraction + reciprocal-multiply division (each quotient  */
+                         /* within ~1 ulp instead of correctly rounded).  Not bit-identical;*/
+                         /* tested against the reference goldens at rtol 1e-12.            */
 
 typedef struct pcl_solver pcl_solver;
 

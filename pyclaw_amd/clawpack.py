@@ -55,6 +55,9 @@ class ClawSolver(Solver):
         self._default_attr_values['verbosity'] = 0
         self._default_attr_values['cfl_max'] = 1.0
         self._default_attr_values['cfl_desired'] = 0.9
+        # arithmetic mode of the HIP kernels: 'exact' (bit-identical to the reference's
+        # no-FMA Fortran) or 'fast' (FMA + reciprocal-multiply divisions, rtol 1e-12)
+        self._default_attr_values['math'] = 'exact'
         self.rp = None
         super(ClawSolver, self).__init__(data)
 
@@ -192,7 +195,9 @@ class ClawSolver(Solver):
             cfg.rp_params[k] = v
         from . import parallel
         cfg.device = parallel.local_rank() if state.decomp is not None else int(getattr(self, 'device', 0))
-        cfg.math = 0
+        if self.math not in ('exact', 'fast'):
+            raise Exception("solver.math must be 'exact' or 'fast'")
+        cfg.math = 1 if self.math == 'fast' else 0
         import ctypes
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().pcl_create(ctypes.byref(cfg), ctypes.byref(h)))

@@ -20,28 +20,11 @@
 #include "rp.hpp"
 
 namespace pcl {
+namespace PCL_NS {
 
 constexpr int WAVE = 64;
-constexpr int PCL_MAX_WAVES_K = 8;      // == PCL_MAX_WAVES of the C ABI
 constexpr int HALO = 2;                 // cells of stencil reach on each side
 constexpr int STRIP = WAVE - 2 * HALO;  // cells updated per wavefront strip
-
-struct SweepArgs {
-    const double *qin;
-    double *qout;
-    const double *aux;
-    long pitch;       // doubles between rows
-    long plane;       // doubles between components
-    int I, J;         // cells per row / rows, ghost cells included
-    int mbc, mx, my;  // interior extents
-    int mcapa;        // 0 = none, else 1-based aux component (method(6))
-    int order;        // method(2)
-    int mthlim[PCL_MAX_WAVES_K];
-    double dtd;       // dt/dx of the sweep direction
-    double dt, dx;    // separately, for the 1-D capa form dt/(dx*capa) (step1.f:70)
-    RpParams par;
-    unsigned long long *cfl;  // device word holding the running max (as ordered bits)
-};
 
 // ---- wavefront neighbour shifts ------------------------------------------------------
 // bound_ctrl:0 => the lane without a source (lane 0 / lane 63) reads 0 and no "old" value has
@@ -70,11 +53,11 @@ template <class T> __device__ __forceinline__ T struct_from_left(const T &t) {
 
 // philim.f:19-55
 __device__ __forceinline__ double philim(double a, double b, int meth) {
-    const double r = b / a;
+    const double r = fdiv(b, a);
     switch (meth) {
     case 1: return dmax(0.0, dmin(1.0, r));
     case 2: return dmax(dmax(0.0, dmin(1.0, 2.0 * r)), dmin(2.0, r));
-    case 3: return (r + fabs(r)) / (1.0 + fabs(r));
+    case 3: return fdiv(r + fabs(r), 1.0 + fabs(r));
     case 4: { const double c = (1.0 + r) / 2.0; return dmax(0.0, dmin(dmin(c, 2.0), 2.0 * r)); }
     case 5: return r;
     }
@@ -318,4 +301,5 @@ __global__ __launch_bounds__(256) void sweep_y_kernel(SweepArgs a, int ntiles_i)
     cfl_publish(a.cfl, cflmax);
 }
 
+}  // namespace PCL_NS
 }  // namespace pcl

@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "../../include/pyclaw_amd.h"
-#include "classic.hpp"
+#include "sweep_args.hpp"
 #include "halo.hpp"
 
 namespace {
@@ -51,6 +51,8 @@ struct pcl_solver {
     long kt_n[2] = {0, 0};
     pcl::Halo halo;
 };
+
+namespace pcl { namespace exact { void launch_shift_test(const double *in, double *l, double *r); } }
 
 namespace {
 
@@ -143,13 +145,6 @@ __global__ void src_euler_radial(double *q, const double *aux, int mbc, int mx, 
     q[3 * plane + g] = q3 - k1 * v * (s3 + press);
 }
 
-__global__ void shift_test_kernel(const double *in, double *l, double *r) {
-    const int t = threadIdx.x;
-    const double x = in[t];
-    l[t] = from_left(x);
-    r[t] = from_right(x);
-}
-
 // ---- sweep dispatch ---------------------------------------------------------------------------
 SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, double dt) {
     SweepArgs a;
@@ -173,38 +168,6 @@ SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, dou
     for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) a.par.v[k] = s->cfg.rp_params[k];
     a.cfl = s->cfl_dev;
     return a;
-}
-
-template <class RP, bool DIM1> int launch_x(pcl_solver *s, const SweepArgs &a) {
-    const int nstrips = (a.mx + STRIP - 1) / STRIP;
-    const int wpb = 4;
-    if (a.J > 65535) return fail(PCL_EINVAL, "more than 65535 rows");
-    const dim3 grid((unsigned)((nstrips + wpb - 1) / wpb), (unsigned)a.J);
-    const bool capa = a.mcapa > 0;
-    if (s->cfg.fwave) return fail(PCL_EINVAL, "fwave: no f-wave Riemann solver is built in yet");
-    if (capa)
-        hipLaunchKernelGGL((sweep_x_kernel<RP, true, false, DIM1>), grid, dim3(256), 0, s->stream,
-                           a, nstrips);
-    else
-        hipLaunchKernelGGL((sweep_x_kernel<RP, false, false, DIM1>), grid, dim3(256), 0,
-                           s->stream, a, nstrips);
-    HIP_TRY(hipGetLastError());
-    return PCL_OK;
-}
-template <class RP> int launch_y(pcl_solver *s, const SweepArgs &a) {
-    const int ntiles_i = (a.I + YT_COLS - 1) / YT_COLS;
-    const int ntiles_j = (a.my + STRIP - 1) / STRIP;
-    const unsigned grid = (unsigned)ntiles_i * (unsigned)ntiles_j;
-    const bool capa = a.mcapa > 0;
-    if (s->cfg.fwave) return fail(PCL_EINVAL, "fwave: no f-wave Riemann solver is built in yet");
-    if (capa)
-        hipLaunchKernelGGL((sweep_y_kernel<RP, true, false>), dim3(grid), dim3(256), 0, s->stream, a,
-                           ntiles_i);
-    else
-        hipLaunchKernelGGL((sweep_y_kernel<RP, false, false>), dim3(grid), dim3(256), 0, s->stream, a,
-                           ntiles_i);
-    HIP_TRY(hipGetLastError());
-    return PCL_OK;
 }
 
 hipEvent_t get_event(pcl_solver *s) {
@@ -243,21 +206,16 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt)
         t.which = ids - 1;
         hipEventRecord(t.a, s->stream);
     }
-    int rc = PCL_EINVAL;
-    const int rp = s->cfg.rp;
-    if (s->cfg.ndim == 1) {
-        if (rp == PCL_RP_ADVECTION_1D) rc = launch_x<Advection1D, true>(s, a);
-        else if (rp == PCL_RP_ACOUSTICS_1D) rc = launch_x<Acoustics1D, true>(s, a);
-        else rc = fail(PCL_EINVAL, "Riemann solver id is not a 1-D solver");
-    } else if (ids == 1) {
-        if (rp == PCL_RP_ACOUSTICS_2D) rc = launch_x<Acoustics2D, false>(s, a);
-        else if (rp == PCL_RP_EULER5_2D) rc = launch_x<Euler5, false>(s, a);
-        else rc = fail(PCL_EINVAL, "Riemann solver id is not a 2-D solver");
-    } else {
-        if (rp == PCL_RP_ACOUSTICS_2D) rc = launch_y<Acoustics2D>(s, a);
-        else if (rp == PCL_RP_EULER5_2D) rc = launch_y<Euler5>(s, a);
-        else rc = fail(PCL_EINVAL, "Riemann solver id is not a 2-D solver");
-    }
+    SweepLaunch l;
+    l.a = a;
+    l.ndim = s->cfg.ndim;
+    l.rp = s->cfg.rp;
+    l.ids = ids;
+    l.fwave = s->cfg.fwave;
+    l.stream = s->stream;
+    std::string err;
+    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sweep(l, err) : pcl::exact::launch_sweep(l, err);
+    if (rc) fail(rc, err);
     if (s->timing) {
         hipEventRecord(t.b, s->stream);
         s->timed.push_back(t);
@@ -302,7 +260,7 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (cfg->ndim < 1 || cfg->ndim > 2) return fail(PCL_EINVAL, "ndim must be 1 or 2");
     if (cfg->mbc != 2) return fail(PCL_EINVAL, "classic kernels need mbc == 2 (reference default)");
     if (cfg->mwaves < 1 || cfg->mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
-    if (cfg->math != PCL_MATH_EXACT) return fail(PCL_EINVAL, "unknown math mode");
+    if (cfg->math != PCL_MATH_EXACT && cfg->math != PCL_MATH_FAST) return fail(PCL_EINVAL, "unknown math mode");
     int want_meqn = 0, want_mwaves = 0, want_ndim = 0;
     switch (cfg->rp) {
     case PCL_RP_ADVECTION_1D: want_meqn = 1; want_mwaves = 1; want_ndim = 1; break;
@@ -602,7 +560,7 @@ int pcl_debug_wave_shift(const double *in64, double *left64, double *right64) {
     double *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 3 * 64 * sizeof(double)));
     HIP_TRY(hipMemcpy(d, in64, 64 * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(shift_test_kernel, dim3(1), dim3(64), 0, 0, d, d + 64, d + 128);
+    pcl::exact::launch_shift_test(d, d + 64, d + 128);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(left64, d + 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(right64, d + 128, 64 * sizeof(double), hipMemcpyDeviceToHost));

@@ -16,12 +16,14 @@
 //   template<int IXY> transverse(L, R, par, asdq, bmasdq, bpasdq)   (rpt2)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "sweep_args.hpp"
+
+#ifndef PCL_NS
+#error "rp.hpp is compiled once per arithmetic mode: define PCL_NS (exact|fast) and PCL_FAST (0|1)"
+#endif
 
 namespace pcl {
-
-struct RpParams {
-    double v[8];
-};
+namespace PCL_NS {
 
 // dmax1/dmin1 of the Fortran.  v_max_f64/v_min_f64 are one instruction; the compare+select
 // form costs a v_cmp, a 2-wait-state VCC hazard and two v_cndmask.  They differ from the
@@ -67,11 +69,24 @@ struct Recip {
         r = __builtin_fma(y, e, y);
     }
     __device__ __forceinline__ double div(double n) const {
+#if PCL_FAST
+        return n * r;  // r is 1/d to full precision: quotient within ~1 ulp, not correctly rounded
+#else
         const double q = n * r;
         const double e = __builtin_fma(-d, q, n);
         return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), d, n);
+#endif
     }
 };
+
+// a single division: IEEE in exact mode, reciprocal-multiply in fast mode
+__device__ __forceinline__ double fdiv(double n, double d) {
+#if PCL_FAST
+    return n * Recip(d).r;
+#else
+    return n / d;
+#endif
+}
 
 // ------------------------------------------------------------------------------------
 // 1-D advection, q_t + u q_x = 0  (third-party rp1_advection.f, restated)
@@ -211,7 +226,7 @@ struct Euler5 {
         r.u2v2 = r.u * r.u + r.v * r.v;
         const double a2 = gamma1 * (r.enth - .5 * r.u2v2);
         r.a = dsqrt(a2);
-        r.g1a2 = gamma1 / a2;
+        r.g1a2 = fdiv(gamma1, a2);
         r.euv = r.enth - r.u2v2;
         return r;
     }
@@ -229,7 +244,7 @@ struct Euler5 {
         const double delta4 = R.q[3] - L.q[3];
         const double a3 = r.g1a2 * (r.euv * delta1 + u * delta2 + v * delta3 - delta4);
         const double a2 = delta3 - v * delta1;
-        const double a4 = (delta2 + (a - u) * delta1 - a * a3) / (2.0 * a);
+        const double a4 = fdiv(delta2 + (a - u) * delta1 - a * a3, 2.0 * a);
         const double a1 = delta1 - a3 - a4;
 
         wave[0][0] = a1; wave[0][mu] = a1 * (u - a); wave[0][mv] = a1 * v;
@@ -257,7 +272,7 @@ struct Euler5 {
             const double s1 = by_rho1.div(rhou1) - c1;
             double sfract;
             if (s0 < 0.0 && s1 > 0.0)
-                sfract = s0 * (s1 - s[0]) / (s1 - s0);
+                sfract = fdiv(s0 * (s1 - s[0]), s1 - s0);
             else if (s[0] < 0.0)
                 sfract = s[0];
             else
@@ -282,7 +297,7 @@ struct Euler5 {
             double sfract = 0.0;
             bool add4 = true;
             if (s2 < 0.0 && s3 > 0.0)
-                sfract = s2 * (s3 - s[3]) / (s3 - s2);
+                sfract = fdiv(s2 * (s3 - s[3]), s3 - s2);
             else if (s[3] < 0.0)
                 sfract = s[3];
             else
@@ -315,7 +330,7 @@ struct Euler5 {
         const double u = r.u, v = r.v, enth = r.enth, a = r.a;
         const double a3 = r.g1a2 * (r.euv * asdq[0] + u * asdq[mu] + v * asdq[mv] - asdq[3]);
         const double a2 = asdq[mu] - u * asdq[0];
-        const double a4 = (asdq[mv] + (a - v) * asdq[0] - a * a3) / (2.0 * a);
+        const double a4 = fdiv(asdq[mv] + (a - v) * asdq[0] - a * a3, 2.0 * a);
         const double a1 = asdq[0] - a3 - a4;
         double wb[4][5], sb[4];
         wb[0][0] = a1; wb[0][mu] = a1 * u; wb[0][mv] = a1 * (v - a);
@@ -337,4 +352,5 @@ struct Euler5 {
     }
 };
 
+}  // namespace PCL_NS
 }  // namespace pcl

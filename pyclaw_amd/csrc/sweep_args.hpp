@@ -1,0 +1,45 @@
+// sweep_args.hpp -- plain launch descriptor shared by the host TU (pclaw.hip) and the two
+// kernel TUs (kernels.hip compiled once per arithmetic mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+
+namespace pcl {
+
+constexpr int MAX_WAVES_K = 8;  // == PCL_MAX_WAVES of the C ABI
+
+struct RpParams {
+    double v[8];
+};
+
+struct SweepArgs {
+    const double *qin;
+    double *qout;
+    const double *aux;
+    long pitch;       // doubles between rows
+    long plane;       // doubles between components
+    int I, J;         // cells per row / rows, ghost cells included
+    int mbc, mx, my;  // interior extents
+    int mcapa;        // 0 = none, else 1-based aux component (method(6))
+    int order;        // method(2)
+    int mthlim[MAX_WAVES_K];
+    double dtd;       // dt/dx of the sweep direction
+    double dt, dx;    // separately, for the 1-D capa form dt/(dx*capa) (step1.f:70)
+    RpParams par;
+    unsigned long long *cfl;  // device word holding the running max (as ordered bits)
+};
+
+struct SweepLaunch {
+    SweepArgs a;
+    int ndim;   // 1 or 2
+    int rp;     // PCL_RP_*
+    int ids;    // 1 = x pass (or the 1-D step), 2 = y pass
+    int fwave;
+    hipStream_t stream;
+};
+
+// defined in kernels.hip, once per arithmetic mode; returns 0 or a PCL_E* code + message
+namespace exact { int launch_sweep(const SweepLaunch &l, std::string &err); }
+namespace fast { int launch_sweep(const SweepLaunch &l, std::string &err); }
+
+}  // namespace pcl

@@ -74,3 +74,28 @@ def test_advection1d_c1(coracle):
     p = D.advection1d_problem(1000)
     D.run(p, coracle, 1.0, 10)
     assert np.array_equal(claw.frames[10].state.q, p.q)
+
+
+# ---- PCL_MATH_FAST: FMA + reciprocal-multiply division.  Not bit-identical; the north-star
+# ---- tolerance is rtol = 1e-12 against the reference.
+RTOL = 1e-12
+
+
+def test_shockbubble_golden_fast(golden_dir):
+    import pyclaw_amd as pyclaw
+    claw = problems.shockbubble(pyclaw, math='fast')
+    dens = claw.frames[claw.nout].state.q[0, :, :]
+    gold = np.loadtxt(os.path.join(golden_dir, "sb_density"))
+    assert claw.solver.status['numsteps'] == 170
+    assert np.max(np.abs(dens - gold)) < 1e-12                 # the reference's own gate
+    assert np.max(np.abs(dens - gold) / np.abs(gold)) < RTOL
+
+
+def test_acoustics2d_fast(coracle):
+    import pyclaw_amd as pyclaw
+    claw = problems.acoustics2D(pyclaw, math='fast')
+    p = D.acoustics2d_problem()
+    D.run(p, coracle, 0.12, 10)
+    q = claw.frames[claw.nout].state.q
+    scale = np.abs(p.q).max()
+    assert np.max(np.abs(q - p.q)) < RTOL * scale
