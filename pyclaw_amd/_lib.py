@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyclaw_amd.so")
+LIB_PATH = os.environ.get("PCL_LIB_OVERRIDE") or os.path.join(_HERE, "libpyclaw_amd.so")   # override: A/B builds in tools/kbench.py
 
 MAX_WAVES = 8
 MAX_RP_PARAMS = 8

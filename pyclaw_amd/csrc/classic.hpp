@@ -30,6 +30,24 @@ constexpr int STRIP = WAVE - 2 * HALO;  // cells updated per wavefront strip
 // bound_ctrl:0 => the lane without a source (lane 0 / lane 63) reads 0 and no "old" value has
 // to be kept alive, so the shift is a single v_mov_b32_dpp per dword.  Those end lanes
 // never feed a stored result (only lanes 2..61 are written).
+#ifndef PCL_SHIFT_LDS
+#define PCL_SHIFT_LDS 0
+#endif
+#if PCL_SHIFT_LDS
+// ds_bpermute_b32: the shift runs on the LDS crossbar (no LDS memory), off the VALU pipe.
+__device__ __forceinline__ double from_left(double x) {  // lane l <- lane l-1
+    const int addr = (((int)threadIdx.x & (WAVE - 1)) - 1) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_right(double x) {  // lane l <- lane l+1
+    const int addr = (((int)threadIdx.x & (WAVE - 1)) + 1) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+#else
 __device__ __forceinline__ double from_left(double x) {  // lane l <- lane l-1 (lane 0 gets 0)
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
@@ -42,6 +60,7 @@ __device__ __forceinline__ double from_right(double x) {  // lane l <- lane l+1 
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+#endif
 template <class T> __device__ __forceinline__ T struct_from_left(const T &t) {
     constexpr int N = sizeof(T) / sizeof(double);
     union U { T t; double d[N]; __device__ U() {} } a, b;
@@ -53,11 +72,11 @@ template <class T> __device__ __forceinline__ T struct_from_left(const T &t) {
 
 // philim.f:19-55
 __device__ __forceinline__ double philim(double a, double b, int meth) {
-    const double r = fdiv(b, a);
+    const double r = fdiv_ieee(b, a);
     switch (meth) {
     case 1: return dmax(0.0, dmin(1.0, r));
     case 2: return dmax(dmax(0.0, dmin(1.0, 2.0 * r)), dmin(2.0, r));
-    case 3: return fdiv(r + fabs(r), 1.0 + fabs(r));
+    case 3: return fdiv_ieee(r + fabs(r), 1.0 + fabs(r));
     case 4: { const double c = (1.0 + r) / 2.0; return dmax(0.0, dmin(dmin(c, 2.0), 2.0 * r)); }
     case 5: return r;
     }
@@ -180,122 +199,175 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
     }
 }
 
-// ---- x pass: rows straight from HBM --------------------------------------------------------
-// grid: one wavefront per (row, strip); 4 wavefronts per workgroup.
-// Covers step2ds ids=1 (all rows incl. ghost rows) and the 1-D step (J == 1).
-template <class RP, bool CAPA, bool FWAVE, bool DIM1>
-__global__ __launch_bounds__(256) void sweep_x_kernel(SweepArgs a, int nstrips) {
-    constexpr int MEQN = RP::MEQN;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int row = blockIdx.y;
-    const int strip = blockIdx.x * (256 / WAVE) + (threadIdx.x / WAVE);
-    if (strip >= nstrips) return;  // whole wavefront leaves together
-    const int c0 = a.mbc - HALO + strip * STRIP;
-    const int c = c0 + lane;
-    const int cc = c < a.I ? c : a.I - 1;  // clamp: lanes past the row end recompute the last cell
-    const long base = (long)row * a.pitch + cc;
-
-    double q[MEQN], qn[MEQN];
-#pragma unroll
-    for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + base];
-    double capa = 1.0, dtdx_c = a.dtd;
-    if (CAPA) {
-        capa = a.aux[(long)(a.mcapa - 1) * a.plane + base];
-        dtdx_c = DIM1 ? a.dt / (a.dx * capa) : a.dtd / capa;
+// ---- the sweep kernel: tiles staged through LDS ------------------------------------------------
+// One workgroup (4 wavefronts) owns a tile; all 256 threads first pull the tile in with ~20
+// independent 8-byte loads each (~40 KB in flight per workgroup, 3-4 workgroups per CU: that
+// memory-level parallelism is what lets a pass stream at ~5 TB/s; a wavefront loading only
+// its own 64 cells tops out near 3.9 TB/s), then every wavefront runs the lane-per-cell core
+// on 4 of the tile's 16 strips, writing results back into the tile in place, and finally
+// all threads store the tile.
+//
+// Every global store (and almost every load) is a whole 128-byte line: rows are laid out so
+// that the first INTERIOR cell of a row is 128-byte aligned (the array base is shifted by
+// LEAD = 16-mbc doubles, see pclaw.hip), and tile edges in the contiguous direction fall on
+// multiples of 16 cells from there.  Unaligned 480-byte row pieces cost ~35 % of the
+// achievable bandwidth on this part.
+//   x pass (IXY=1): along = i (contiguous).  Tile = 4 rows x 244 cells (4 strips of 60 + halo):
+//       240 = 15 x 16 updated cells per row.  LDS tile[m][row][244].  Wavefront w owns row w
+//       and walks its 4 strips left to right.
+//   y pass (IXY=2): along = j, across = i (contiguous).  Tile = 64 rows x 16 columns, one strip
+//       per column.  LDS tile[m][row][17] (pitch 17: conflict-free column reads).  Wavefront w
+//       owns columns w, w+4, w+8, w+12.
+// step2ds semantics: the x pass sweeps every row (ghost rows too) and copies ghost columns
+// through; the y pass sweeps every column and copies ghost rows through.
+template <int IXY> struct TileShape {
+    static constexpr int NSTRIP = IXY == 1 ? 4 : 1;                 // strips along the sweep per tile
+    static constexpr int ALONG = NSTRIP * STRIP + 2 * HALO;         // cells loaded along the sweep
+    static constexpr int ACROSS = IXY == 1 ? 4 : 16;                // cells across
+    static constexpr int PLANE = IXY == 1 ? ACROSS * ALONG : ALONG * (ACROSS + 1);
+    static constexpr int UNITS = NSTRIP * ACROSS / 4;               // strips per wavefront
+    __device__ static __forceinline__ int at(int m, int al, int ac) {
+        return IXY == 1 ? (m * ACROSS + ac) * ALONG + al : (m * ALONG + al) * (ACROSS + 1) + ac;
     }
-    const bool interior = (c >= a.mbc) && (c < a.mbc + a.mx);
-    const bool cfl_ok = (c >= a.mbc) && (c <= a.mbc + a.mx) && lane >= 1;
-    double cflmax = 0.0;
-    lane_core<RP, 1, CAPA, FWAVE, DIM1>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax);
+};
+constexpr int LINE = 16;  // doubles per 128-byte line
 
-    if (c < a.I) {
-        if (interior) {
-            if (lane >= HALO && lane < WAVE - HALO) {
+template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1>
+__global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
+    using T = TileShape<IXY>;
+    constexpr int MEQN = RP::MEQN;
+    constexpr int NP = MEQN + (CAPA ? 1 : 0);
+    __shared__ double tile[NP * T::PLANE];
+
+    // extents of the swept (along) and transverse (across) directions, ghost cells included
+    const int n_along = IXY == 1 ? a.I : a.J;
+    const int n_across = IXY == 1 ? a.J : a.I;
+    const int m_along = IXY == 1 ? a.mx : a.my;  // interior cells along the sweep
+    // Block order: the memory-contiguous direction varies fastest, so the workgroups in flight at
+    // any moment stream whole rows.  (With the across index fastest in the x pass, all resident
+    // workgroups read the same 2 KB column band of ~1000 rows whose pitch is 32 KB + 128 B: the
+    // requests pile up on a few HBM channels and the pass drops to ~3.9 TB/s even as a pure copy.)
+    const int tb = IXY == 1 ? blockIdx.x / ntiles_along : blockIdx.x % ntiles_across;
+    const int ta = IXY == 1 ? blockIdx.x % ntiles_along : blockIdx.x / ntiles_across;
+    // y pass: column tiles start LEAD cells before cell 0 so that they sit on 128-byte lines
+    const int b0 = IXY == 1 ? tb * T::ACROSS : tb * T::ACROSS - (LINE - a.mbc);
+    const int a0 = a.mbc - HALO + ta * (T::NSTRIP * STRIP);
+
+    // ---- cooperative load ------------------------------------------------------------------
+    if (IXY == 1) {
+        const int al = threadIdx.x;
+        if (al < T::ALONG) {
+            int ga = a0 + al;
+            ga = ga < n_along ? ga : n_along - 1;  // clamp: cells past the edge repeat the last one
 #pragma unroll
-                for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + base] = qn[m];
+            for (int ac = 0; ac < T::ACROSS; ac++) {
+                int gb = b0 + ac;
+                gb = gb < n_across ? gb : n_across - 1;
+                const long g = (long)gb * a.pitch + ga;
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = a.qin[m * a.plane + g];
+                if constexpr (CAPA) tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
             }
-        } else {  // ghost columns keep their value (qnew starts as a copy of qold)
-#pragma unroll
-            for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + base] = q[m];
         }
-    }
-    cfl_publish(a.cfl, cflmax);
-}
-
-// ---- y pass: 64-row x 16-column tiles through LDS ---------------------------------------------
-// step2ds ids=2: every column (ghost columns too), rows 1..my updated, ghost rows copied.
-constexpr int YT_COLS = 16;
-constexpr int YT_PITCH = YT_COLS + 1;  // +1 double: conflict-free column reads
-
-template <class RP, bool CAPA, bool FWAVE>
-__global__ __launch_bounds__(256) void sweep_y_kernel(SweepArgs a, int ntiles_i) {
-    constexpr int MEQN = RP::MEQN;
-    constexpr int NP = MEQN + 1;  // last plane: capa (only touched when CAPA)
-    constexpr int NPA = CAPA ? NP : MEQN;
-    __shared__ double tile[NPA][WAVE][YT_PITCH];
-
-    const int ti = blockIdx.x % ntiles_i;
-    const int tj = blockIdx.x / ntiles_i;
-    const int i0 = ti * YT_COLS;
-    const int j0 = a.mbc - HALO + tj * STRIP;
-
-    // load: 16 lanes cover one 128-byte row segment
-    {
-        const int lc = threadIdx.x % YT_COLS;
-        const int lr = threadIdx.x / YT_COLS;  // 0..15
-        const int i = i0 + lc;
-        const int ic = i < a.I ? i : a.I - 1;
+    } else {
+        const int ac = threadIdx.x % T::ACROSS;
+        int gb = b0 + ac;
+        gb = gb < 0 ? 0 : (gb < n_across ? gb : n_across - 1);
 #pragma unroll
-        for (int rr = 0; rr < WAVE; rr += 256 / YT_COLS) {
-            const int r = rr + lr;
-            const int j = j0 + r;
-            const int jc = j < a.J ? j : a.J - 1;
-            const long g = (long)jc * a.pitch + ic;
+        for (int k = 0; k < T::ALONG; k += 256 / T::ACROSS) {
+            const int al = k + threadIdx.x / T::ACROSS;
+            int ga = a0 + al;
+            ga = ga < n_along ? ga : n_along - 1;
+            const long g = (long)ga * a.pitch + gb;
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) tile[m][r][lc] = a.qin[m * a.plane + g];
-            if constexpr (CAPA) tile[NPA - 1][r][lc] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
+            for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = a.qin[m * a.plane + g];
+            if constexpr (CAPA) tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
         }
     }
     __syncthreads();
 
+    // ---- arithmetic: each wavefront walks its UNITS strips ---------------------------------------
+    // The strips of one row (x pass) overlap by 2*HALO cells inside the tile and results go back
+    // in place, so a strip's cells are read into registers BEFORE the previous strip's results
+    // are written (one-deep software pipeline; the same wavefront owns the whole row).
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
-    const int j = j0 + lane;
-    const bool interior = (j >= a.mbc) && (j < a.mbc + a.my);
-    const bool cfl_row = (j >= a.mbc) && (j <= a.mbc + a.my) && lane >= 1;
+    auto unit_ac = [&](int u) { return IXY == 1 ? wv : wv + 4 * u; };
+    auto unit_al = [&](int u) { return (IXY == 1 ? u * STRIP : 0) + lane; };
+    auto unit_live = [&](int u) {  // wave-uniform
+        const int gb = b0 + unit_ac(u);
+        const bool across_ok = gb >= 0 && gb < n_across;
+        const bool along_ok = a0 + (IXY == 1 ? u * STRIP : 0) + HALO < a.mbc + m_along;  // not all past the interior
+        return u < T::UNITS && across_ok && along_ok;
+    };
     double cflmax = 0.0;
-    for (int col = wv; col < YT_COLS; col += 256 / WAVE) {
-        if (i0 + col >= a.I) break;  // wave-uniform
-        double q[MEQN], qn[MEQN];
+    double qnext[MEQN], capanext = 1.0;
+    bool have_next = false;  // wave-uniform: qnext holds unit u's cells
 #pragma unroll
-        for (int m = 0; m < MEQN; m++) q[m] = tile[m][lane][col];
-        double capa = 1.0, dtdx_c = a.dtd;
-        if constexpr (CAPA) { capa = tile[NPA - 1][lane][col]; dtdx_c = a.dtd / capa; }
-        lane_core<RP, 2, CAPA, FWAVE, false>(q, dtdx_c, capa, cfl_row, a, qn, cflmax);
-        // only this lane ever reads tile[.][lane][col]: update in place
-        if (interior && lane >= HALO && lane < WAVE - HALO) {
+    for (int u = 0; u < T::UNITS; u++) {
+        if (!unit_live(u)) { have_next = false; continue; }  // wave-uniform
+        const int al = unit_al(u), ac = unit_ac(u);
+        const int ca = a0 + al;  // this lane's cell index along the sweep
+        const bool owned = (ca >= a.mbc) && (ca < a.mbc + m_along) && lane >= HALO && lane < WAVE - HALO;
+        const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + m_along) && lane >= 1;
+        double q[MEQN], qn[MEQN], capa = 1.0, dtdx_c = a.dtd;
+        if (have_next) {
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) tile[m][lane][col] = qn[m];
+            for (int m = 0; m < MEQN; m++) q[m] = qnext[m];
+            capa = capanext;
+        } else {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) q[m] = tile[T::at(m, al, ac)];
+            if constexpr (CAPA) capa = tile[T::at(MEQN, al, ac)];
+        }
+        have_next = unit_live(u + 1);
+        if (have_next) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) qnext[m] = tile[T::at(m, unit_al(u + 1), unit_ac(u + 1))];
+            if constexpr (CAPA) capanext = tile[T::at(MEQN, unit_al(u + 1), unit_ac(u + 1))];
+        }
+        if constexpr (CAPA) dtdx_c = DIM1 ? a.dt / (a.dx * capa) : a.dtd / capa;
+        if (a.ablate & 1) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) qn[m] = q[m];
+        } else
+            lane_core<RP, IXY, CAPA, FWAVE, DIM1>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax);
+        if (owned) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = qn[m];
         }
     }
     __syncthreads();
 
-    // store: interior rows owned by this tile (lanes 2..61) + ghost rows (copied through)
-    {
-        const int lc = threadIdx.x % YT_COLS;
-        const int lr = threadIdx.x / YT_COLS;
-        const int i = i0 + lc;
+    // ---- cooperative store: owned interior cells + ghost cells along the sweep (copied through) ----
+    auto put = [&](int al, int ac) {
+        const int ga = a0 + al, gb = b0 + ac;
+        if (ga < n_along && gb >= 0 && gb < n_across) {
+            const long g = IXY == 1 ? (long)gb * a.pitch + ga : (long)ga * a.pitch + gb;
 #pragma unroll
-        for (int rr = 0; rr < WAVE; rr += 256 / YT_COLS) {
-            const int r = rr + lr;
-            const int jj = j0 + r;
-            const bool inner = (jj >= a.mbc) && (jj < a.mbc + a.my);
-            const bool mine = inner ? (r >= HALO && r < WAVE - HALO) : true;
-            if (i < a.I && jj < a.J && mine) {
-                const long g = (long)jj * a.pitch + i;
+            for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[T::at(m, al, ac)];
+        }
+    };
+    if (IXY == 1) {
+        const int t = threadIdx.x;
+        if (t < T::NSTRIP * STRIP) {  // cells a0+2 .. a0+241: 15 whole lines per row
 #pragma unroll
-                for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[m][r][lc];
-            }
+            for (int ac = 0; ac < T::ACROSS; ac++) put(HALO + t, ac);
+        } else if (t < T::NSTRIP * STRIP + 2 * HALO) {  // the tile's own halo cells, only where they are ghosts
+            const int k = t - T::NSTRIP * STRIP;
+            const int al = k < HALO ? k : T::ALONG - 2 * HALO + k;
+            const int ga = a0 + al;
+            if (ga < a.mbc || ga >= a.mbc + m_along)
+                for (int ac = 0; ac < T::ACROSS; ac++) put(al, ac);
+        }
+    } else {
+        const int ac = threadIdx.x % T::ACROSS;
+#pragma unroll
+        for (int k = 0; k < T::ALONG; k += 256 / T::ACROSS) {
+            const int al = k + threadIdx.x / T::ACROSS;
+            const int ga = a0 + al;
+            const bool inner = (ga >= a.mbc) && (ga < a.mbc + m_along);
+            if (inner ? (al >= HALO && al < T::ALONG - HALO) : true) put(al, ac);
         }
     }
     cfl_publish(a.cfl, cflmax);

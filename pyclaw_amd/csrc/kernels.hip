@@ -5,6 +5,7 @@
 //                                                   division; checked at rtol 1e-12
 // Distinct namespaces keep the two sets of template instantiations apart at link time.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/pyclaw_amd.h"
@@ -20,31 +21,22 @@ int hip_fail(std::string &err, const char *what, hipError_t e) {
     return PCL_EHIP;
 }
 
-template <class RP, bool DIM1> int launch_x(const SweepLaunch &l, std::string &err) {
+template <class RP, int IXY, bool DIM1> int launch(const SweepLaunch &l, std::string &err) {
+    using T = TileShape<IXY>;
     const SweepArgs &a = l.a;
-    const int nstrips = (a.mx + STRIP - 1) / STRIP;
-    const int wpb = 4;
-    if (a.J > 65535) { err = "more than 65535 rows"; return PCL_EINVAL; }
-    const dim3 grid((unsigned)((nstrips + wpb - 1) / wpb), (unsigned)a.J);
+    const int n_across = IXY == 1 ? a.J : a.I + (LINE - a.mbc);  // y: columns counted from the line boundary
+    const int m_along = IXY == 1 ? a.mx : a.my;
+    const int ntiles_across = (n_across + T::ACROSS - 1) / T::ACROSS;
+    const int ntiles_along = (m_along + T::NSTRIP * STRIP - 1) / (T::NSTRIP * STRIP);
+    const dim3 grid((unsigned)ntiles_across * (unsigned)ntiles_along);
     if (a.mcapa > 0)
-        hipLaunchKernelGGL((sweep_x_kernel<RP, true, false, DIM1>), grid, dim3(256), 0, l.stream, a, nstrips);
+        hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, false, DIM1>), grid, dim3(256), 0, l.stream, a,
+                           ntiles_across, ntiles_along);
     else
-        hipLaunchKernelGGL((sweep_x_kernel<RP, false, false, DIM1>), grid, dim3(256), 0, l.stream, a, nstrips);
+        hipLaunchKernelGGL((sweep_kernel<RP, IXY, false, false, DIM1>), grid, dim3(256), 0, l.stream, a,
+                           ntiles_across, ntiles_along);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep_x launch", e);
-}
-
-template <class RP> int launch_y(const SweepLaunch &l, std::string &err) {
-    const SweepArgs &a = l.a;
-    const int ntiles_i = (a.I + YT_COLS - 1) / YT_COLS;
-    const int ntiles_j = (a.my + STRIP - 1) / STRIP;
-    const unsigned grid = (unsigned)ntiles_i * (unsigned)ntiles_j;
-    if (a.mcapa > 0)
-        hipLaunchKernelGGL((sweep_y_kernel<RP, true, false>), dim3(grid), dim3(256), 0, l.stream, a, ntiles_i);
-    else
-        hipLaunchKernelGGL((sweep_y_kernel<RP, false, false>), dim3(grid), dim3(256), 0, l.stream, a, ntiles_i);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep_y launch", e);
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep launch", e);
 }
 
 }  // namespace
@@ -54,17 +46,17 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
     if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
     const int rp = l.rp;
     if (l.ndim == 1) {
-        if (rp == PCL_RP_ADVECTION_1D) return launch_x<Advection1D, true>(l, err);
-        if (rp == PCL_RP_ACOUSTICS_1D) return launch_x<Acoustics1D, true>(l, err);
+        if (rp == PCL_RP_ADVECTION_1D) return launch<Advection1D, 1, true>(l, err);
+        if (rp == PCL_RP_ACOUSTICS_1D) return launch<Acoustics1D, 1, true>(l, err);
         err = "Riemann solver id is not a 1-D solver";
         return PCL_EINVAL;
     }
     if (l.ids == 1) {
-        if (rp == PCL_RP_ACOUSTICS_2D) return launch_x<Acoustics2D, false>(l, err);
-        if (rp == PCL_RP_EULER5_2D) return launch_x<Euler5, false>(l, err);
+        if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false>(l, err);
+        if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false>(l, err);
     } else {
-        if (rp == PCL_RP_ACOUSTICS_2D) return launch_y<Acoustics2D>(l, err);
-        if (rp == PCL_RP_EULER5_2D) return launch_y<Euler5>(l, err);
+        if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false>(l, err);
+        if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
     return PCL_EINVAL;

@@ -2,6 +2,7 @@
 // gfx950 only.  No CPU fallback: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -34,6 +35,8 @@ struct pcl_solver {
     int I = 1, J = 1;     // cells incl. ghosts
     long pitch = 0, plane = 0, total = 0;  // doubles
     long aplane = 0;
+    int lead = 0;         // doubles the array bases are shifted by so that the first interior
+                          // cell of every row starts a 128-byte line (16 - mbc)
     double *q = nullptr, *t1 = nullptr, *t2 = nullptr, *bak = nullptr;
     double *aux = nullptr;
     double *stage = nullptr;  // AoS staging for host transfers (qbc-sized)
@@ -167,6 +170,8 @@ SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, dou
     a.dtd = dt / s->cfg.d[ids - 1];
     for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) a.par.v[k] = s->cfg.rp_params[k];
     a.cfl = s->cfl_dev;
+    static const int ablate = [] { const char *e = getenv("PCL_TUNE_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = ablate;
     return a;
 }
 
@@ -285,11 +290,17 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     s->plane = s->pitch * s->J;
     s->total = s->plane * cfg->meqn;
     const size_t qbytes = (size_t)s->total * sizeof(double);
-    hipError_t e = hipSuccess;
+    // every buffer is zero-filled ON THE SOLVER'S STREAM: a null-stream hipMemset is not
+    // ordered against this non-blocking stream and could land after the first upload
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    s->lead = 16 - cfg->mbc;
     auto alloc = [&](double **p, size_t bytes) {
         if (e != hipSuccess) return;
-        e = hipMalloc((void **)p, bytes);
-        if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+        double *raw = nullptr;
+        bytes += 16 * sizeof(double);
+        e = hipMalloc((void **)&raw, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(raw, 0, bytes, s->stream);
+        if (e == hipSuccess) *p = raw + s->lead;
     };
     alloc(&s->q, qbytes);
     alloc(&s->t1, qbytes);
@@ -300,9 +311,9 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     alloc(&s->stage, s->stage_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&s->cfl_dev, 64);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->cfl_host, 64, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) {
         std::string msg = std::string("pcl_create: ") + hipGetErrorString(e);
         pcl_destroy(s);
@@ -319,8 +330,9 @@ void pcl_destroy(pcl_solver *s) {
     s->halo.destroy();
     for (auto &t : s->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto &e : s->evpool) hipEventDestroy(e);
-    hipFree(s->q); hipFree(s->t1); hipFree(s->t2); hipFree(s->bak); hipFree(s->aux);
-    hipFree(s->stage); hipFree(s->cfl_dev);
+    for (double *p : {s->q, s->t1, s->t2, s->bak, s->aux, s->stage})
+        if (p) hipFree(p - s->lead);
+    hipFree(s->cfl_dev);
     if (s->cfl_host) hipHostFree(s->cfl_host);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
@@ -490,7 +502,11 @@ int pcl_backup(pcl_solver *s) {
     if (!s) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     const size_t qbytes = (size_t)s->total * sizeof(double);
-    if (!s->bak) HIP_TRY(hipMalloc((void **)&s->bak, qbytes));
+    if (!s->bak) {
+        double *raw = nullptr;
+        HIP_TRY(hipMalloc((void **)&raw, qbytes + 16 * sizeof(double)));
+        s->bak = raw + s->lead;
+    }
     HIP_TRY(hipMemcpyAsync(s->bak, s->q, qbytes, hipMemcpyDeviceToDevice, s->stream));
     return PCL_OK;
 }

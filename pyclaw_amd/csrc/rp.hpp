@@ -50,15 +50,21 @@ __device__ __forceinline__ double dsqrt(double x) {
     return __builtin_amdgcn_class(x, 0x260) ? x : g;  // +-0, +inf pass through
 }
 
-// ---- division by a shared denominator ----------------------------------------------------
-// The reference divides several numerators by the same value (q/rho, q/sqrt(rho), ./rhsq2).
-// hipcc expands every IEEE f64 division into: 2 v_div_scale, v_rcp_f64, 4 fma (Newton on the
-// reciprocal), mul, fma, v_div_fmas, v_div_fixup.  The reciprocal part depends on the
-// denominator only, so it is computed once; each quotient then costs mul + 2 fma + fixup.
-// The quotient is the same correctly rounded value (Markstein: q' = fma(fma(-d,q,n), r, q)
-// with r within 1 ulp of 1/d) as long as no operand needs v_div_scale's range scaling,
-// i.e. exponents stay away from the ends of the double range (|x| in 2^-700 .. 2^700);
-// zero / inf / NaN operands are still handled by v_div_fixup exactly like the full form.
+// ---- division ------------------------------------------------------------------------------
+// hipcc expands an IEEE f64 division into 2 v_div_scale, v_rcp_f64, 4 fma (Newton on the
+// reciprocal), mul, fma, v_div_fmas, v_div_fixup: 11 instructions, 5 of them quarter-rate.
+// Two observations make the Riemann solver's divisions much cheaper with THE SAME BITS:
+//  * the reciprocal refinement depends on the denominator only, and the reference divides
+//    several numerators by the same value (q/rho, q/sqrt(rho), ./rhsq2): refine once;
+//  * v_div_scale / v_div_fmas / v_div_fixup only matter when an operand or the quotient is
+//    outside the normal range (zero, inf, NaN, denormal, |exponent| > ~700).  Densities,
+//    sound speeds and their sums never are, and for normal operands the plain sequence
+//    q0 = n*r, q = fma(fma(-d,q0,n), r, q0) is the same correctly rounded quotient
+//    (Markstein's theorem; r is 1/d to within an ulp after two Newton steps).
+// So: Recip(d) = v_rcp_f64 + 4 fma, each quotient = mul + 2 fma.  Outside the normal range
+// the result differs from IEEE (e.g. n/0 gives NaN instead of inf): only reached by states
+// that are already unphysical.  The limiter ratio (philim), whose operands are sums of
+// squares that can legitimately underflow, keeps the full IEEE division in exact mode.
 struct Recip {
     double d, r;
     __device__ __forceinline__ explicit Recip(double den) : d(den) {
@@ -70,17 +76,19 @@ struct Recip {
     }
     __device__ __forceinline__ double div(double n) const {
 #if PCL_FAST
-        return n * r;  // r is 1/d to full precision: quotient within ~1 ulp, not correctly rounded
+        return n * r;  // within ~1 ulp, not correctly rounded
 #else
         const double q = n * r;
-        const double e = __builtin_fma(-d, q, n);
-        return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), d, n);
+        return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 #endif
     }
 };
 
-// a single division: IEEE in exact mode, reciprocal-multiply in fast mode
-__device__ __forceinline__ double fdiv(double n, double d) {
+// one division of physical (normal-range) quantities
+__device__ __forceinline__ double fdiv(double n, double d) { return Recip(d).div(n); }
+
+// one division with full IEEE semantics in exact mode (any operands)
+__device__ __forceinline__ double fdiv_ieee(double n, double d) {
 #if PCL_FAST
     return n * Recip(d).r;
 #else

@@ -27,6 +27,7 @@ struct SweepArgs {
     double dt, dx;    // separately, for the 1-D capa form dt/(dx*capa) (step1.f:70)
     RpParams par;
     unsigned long long *cfl;  // device word holding the running max (as ordered bits)
+    int ablate;       // diagnostic only (tools/kbench.py): bit0 = skip the arithmetic (copy through)
 };
 
 struct SweepLaunch {
