@@ -178,6 +178,11 @@ int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128],
 int pcl_halo_exchange(pcl_solver *s);          /* faces + corners, width mbc            */
 int pcl_halo_exchange_aux(pcl_solver *s);
 int pcl_allreduce_max(pcl_solver *s, double *value);
+/* Host-only helper (no GPU needed): the cell window [i0,i0+ni) x [j0,j0+nj) of a block of
+ * I x J cells (ghosts included, width mbc) that is SENT towards direction dir (send=1: interior
+ * cells next to that edge/corner) or FILLED from direction dir (send=0: ghost cells).  dir:
+ * 0..7 = W,E,S,N,SW,SE,NW,NE.  Exactly the geometry the device pack/unpack kernels use. */
+int pcl_halo_region(int dir, int send, int I, int J, int mbc, int out_i0_j0_ni_nj[4]);
 
 /* ---- debug / self-test --------------------------------------------------------------- */
 /* Runs the wavefront neighbour-shift primitive on 64 values: left[l]=in[l-1],

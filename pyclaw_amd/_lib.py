@@ -78,6 +78,7 @@ PROTOTYPES = {
     "pcl_halo_exchange": (C.c_int, [C.c_void_p]),
     "pcl_halo_exchange_aux": (C.c_int, [C.c_void_p]),
     "pcl_allreduce_max": (C.c_int, [C.c_void_p, dp]),
+    "pcl_halo_region": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip]),
     "pcl_debug_wave_shift": (C.c_int, [dp, dp, dp]),
 }
 

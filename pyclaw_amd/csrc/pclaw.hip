@@ -669,6 +669,13 @@ int pcl_halo_exchange_aux(pcl_solver *s) {
     return PCL_OK;
 }
 
+int pcl_halo_region(int dir, int send, int I, int J, int mbc, int out[4]) {
+    if (dir < 0 || dir > 7 || !out || mbc < 1 || I <= 2 * mbc || J <= 2 * mbc) return fail(PCL_EINVAL, "bad argument");
+    const pcl::HaloRegion r = pcl::halo_region(dir, send != 0, I, J, mbc);
+    out[0] = r.i0; out[1] = r.j0; out[2] = r.ni; out[3] = r.nj;
+    return PCL_OK;
+}
+
 int pcl_allreduce_max(pcl_solver *s, double *value) {
     if (!s || !value) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));

@@ -1,0 +1,179 @@
+"""
+Worker for tests/test_parallel_cpu.py (launched by torch.distributed.run, gloo, CPU only).
+
+Runs a block-decomposed classic dim-split (or unsplit) computation and checks DECOMPOSITION
+INVARIANCE: the gathered result must equal the serial run bit for bit (the reference asserts
+serial == mpiexec -n 6 at 1e-14, test/test_examples.py:264-277).
+
+What is under test is the PRODUCT's host-side parallel logic:
+  pyclaw_amd.parallel   proc_grid / block ranges / neighbour ranks (periodic wrap rules)
+  pcl_halo_region       strip geometry used by the device pack/unpack kernels (C ABI, host code)
+  the wire protocol     "for d in W,E,S,N,SW,SE,NW,NE: send towards d, receive from opposite(d)"
+  BC placement          physical BCs only on blocks that touch the domain edge, after the halo
+The transport here is gloo on host arrays (the product's is RCCL on device buffers) and the
+per-block arithmetic is the CPU oracle: neither is what is being checked.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import driver as D          # noqa: E402
+from oracle import oracle as O          # noqa: E402
+from pyclaw_amd import _lib, parallel   # noqa: E402
+
+OPP = [1, 0, 3, 2, 7, 6, 5, 4]
+
+
+def region(d, send, I, J, g):
+    o = np.zeros(4, dtype=np.int32)
+    _lib.check(_lib.lib().pcl_halo_region(d, int(send), I, J, g, _lib.i(o)))
+    return slice(o[0], o[0] + o[2]), slice(o[1], o[1] + o[3])
+
+
+def halo_exchange(qbc, nbr, g):
+    I, J = qbc.shape[1:]
+    reqs, recvs = [], []
+    for d in range(8):
+        if nbr[d] >= 0:
+            si, sj = region(d, True, I, J, g)
+            buf = torch.from_numpy(np.ascontiguousarray(qbc[:, si, sj]))
+            reqs.append(dist.isend(buf, dst=int(nbr[d])))
+        o = OPP[d]
+        if nbr[o] >= 0:
+            fi, fj = region(o, False, I, J, g)
+            rb = torch.empty(qbc[:, fi, fj].shape, dtype=torch.float64)
+            reqs.append(dist.irecv(rb, src=int(nbr[o])))
+            recvs.append((fi, fj, rb))
+    for r in reqs:
+        r.wait()
+    for fi, fj, rb in recvs:
+        qbc[:, fi, fj] = rb.numpy()
+
+
+def local_bcs(qbc, g, bc_lower, bc_upper, user_lower, dec, nglob):
+    """solver.py:354-381 on a block: only sides on the physical boundary; a periodic side is a
+    local copy only when this block spans the whole dimension."""
+    for idim in range(2):
+        lo = dec.ranges[idim][0] == 0
+        hi = dec.ranges[idim][1] == nglob[idim]
+        whole = lo and hi
+        v = np.rollaxis(qbc, idim + 1, 1)
+        if lo:
+            bc = bc_lower[idim]
+            if bc == D.CUSTOM:
+                user_lower(idim, 0.0, qbc, g)
+            elif bc == D.OUTFLOW:
+                for i in range(g):
+                    v[:, i, ...] = v[:, g, ...]
+            elif bc == D.REFLECTING:
+                for i in range(g):
+                    v[:, i, ...] = v[:, 2 * g - 1 - i, ...]
+                    v[idim + 1, i, ...] = -v[idim + 1, 2 * g - 1 - i, ...]
+            elif bc == D.PERIODIC and whole:
+                v[:, :g, ...] = v[:, -2 * g:-g, ...]
+        if hi:
+            bc = bc_upper[idim]
+            if bc == D.OUTFLOW:
+                for i in range(g):
+                    v[:, -i - 1, ...] = v[:, -g - 1, ...]
+            elif bc == D.REFLECTING:
+                for i in range(g):
+                    v[:, -i - 1, ...] = v[:, -2 * g + i, ...]
+                    v[idim + 1, -i - 1, ...] = -v[idim + 1, -2 * g + i, ...]
+            elif bc == D.PERIODIC and whole:
+                v[:, -g:, ...] = v[:, g:2 * g, ...]
+
+
+def main():
+    case = sys.argv[1]
+    nsteps = int(sys.argv[2])
+    parallel.init("gloo")
+    rank, size = parallel.rank(), parallel.world_size()
+    be = O.COracle()
+
+    if case == "euler":
+        p = D.shockbubble_problem(mx=48, my=36, with_src=False)
+    elif case == "acoustics_periodic":
+        p = D.acoustics2d_problem(mx=40, my=44, bcs=([D.PERIODIC, D.REFLECTING], [D.PERIODIC, D.OUTFLOW]))
+    elif case == "acoustics_periodic_xy":
+        p = D.acoustics2d_problem(mx=36, my=40, bcs=([D.PERIODIC, D.PERIODIC], [D.PERIODIC, D.PERIODIC]))
+    elif case == "euler_unsplit":
+        p = D.shockbubble_problem(mx=48, my=36, with_src=False, dim_split=False, order_trans=2)
+    else:
+        raise SystemExit("unknown case")
+    D.setup(p)
+    g = p.mbc
+    nglob = list(p.q.shape[1:])
+    dec = parallel.Decomposition(nglob, size, rank)
+    (i0, i1), (j0, j1) = dec.ranges
+    periodic = [p.bc_lower[k] == D.PERIODIC for k in range(2)]
+    nbr = dec.neighbors(periodic)
+    mx, my = i1 - i0, j1 - j0
+    meqn = p.q.shape[0]
+    q = np.array(p.q[:, i0:i1, j0:j1], order="F")
+    qbc = np.zeros((meqn, mx + 2 * g, my + 2 * g), order="F")
+    dt = p.dt_initial
+    for _ in range(nsteps):
+        qbc[:, g:-g, g:-g] = q
+        halo_exchange(qbc, nbr, g)
+        local_bcs(qbc, g, p.bc_lower, p.bc_upper, p.user_bc_lower, dec, nglob)
+        qold = qbc.copy("F")
+        maxm = max(mx, my)
+        if p.dim_split:
+            _, cx = be.step2ds(p.rp, p.rp_params, maxm, g, mx, my, qold, qbc, None, p.d[0], p.d[1], dt,
+                               p.method, p.mthlim, 1)
+            _, cy = be.step2ds(p.rp, p.rp_params, maxm, g, mx, my, qbc, qbc, None, p.d[0], p.d[1], dt,
+                               p.method, p.mthlim, 2)
+            cfl = max(cx, cy)
+        else:
+            _, cfl = be.step2(p.rp, p.rp_params, maxm, g, mx, my, qold, qbc, None, p.d[0], p.d[1], dt,
+                              p.method, p.mthlim)
+        cfl = parallel.allreduce_max_host(cfl)          # petclaw/cfl.py:29-31
+        q = np.array(qbc[:, g:-g, g:-g], order="F")
+        dt = min(p.dt_max, dt * p.cfl_desired / cfl)    # accept unconditionally; dt follows the global CFL
+
+    # gather on rank 0 and compare with the serial computation
+    parts = [None] * size
+    dist.gather_object((i0, i1, j0, j1, q, dt), parts if rank == 0 else None, dst=0)
+    ok = True
+    if rank == 0:
+        full = np.zeros_like(p.q)
+        for (a0, a1, b0, b1, blk, dtk) in parts:
+            full[:, a0:a1, b0:b1] = blk
+            assert dtk == dt
+        # serial reference: same loop on one block
+        sq = np.array(p.q, order="F")
+        sqbc = np.zeros((meqn, nglob[0] + 2 * g, nglob[1] + 2 * g), order="F")
+        sdt = p.dt_initial
+        for _ in range(nsteps):
+            sqbc[:, g:-g, g:-g] = sq
+            D.fill_ghosts(sqbc, g, p.bc_lower, p.bc_upper, p.user_bc_lower, p.user_bc_upper, 0.0)
+            sold = sqbc.copy("F")
+            maxm = max(nglob)
+            if p.dim_split:
+                _, cx = be.step2ds(p.rp, p.rp_params, maxm, g, nglob[0], nglob[1], sold, sqbc, None, p.d[0],
+                                   p.d[1], sdt, p.method, p.mthlim, 1)
+                _, cy = be.step2ds(p.rp, p.rp_params, maxm, g, nglob[0], nglob[1], sqbc, sqbc, None, p.d[0],
+                                   p.d[1], sdt, p.method, p.mthlim, 2)
+                scfl = max(cx, cy)
+            else:
+                _, scfl = be.step2(p.rp, p.rp_params, maxm, g, nglob[0], nglob[1], sold, sqbc, None, p.d[0],
+                                   p.d[1], sdt, p.method, p.mthlim)
+            sq = np.array(sqbc[:, g:-g, g:-g], order="F")
+            sdt = min(p.dt_max, sdt * p.cfl_desired / scfl)
+        ok = bool(np.array_equal(full, sq)) and sdt == dt
+        print("RESULT case=%s size=%d dims=%s equal=%s maxdiff=%g" % (case, size, dec.dims, ok,
+                                                                     np.abs(full - sq).max()))
+    parallel.barrier()
+    parallel.shutdown()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

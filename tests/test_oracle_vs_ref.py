@@ -1,0 +1,103 @@
+"""
+CPU: the oracle's C restatement against the REFERENCE'S OWN FORTRAN (oracle/_ref, flang build of
+step2ds.f/step2.f/flux2.f/limiter.f/philim.f + the vendored Euler 5-wave solvers) on seeded
+random inputs -- bit for bit.  Skipped where oracle/_ref has not been built (it needs the
+reference tree; the GPU box only has the prebuilt file).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.skipif(not O.RefEuler2D.available(), reason="oracle/_ref not built")
+
+
+def euler_state(rng, shape, strong=False):
+    q = np.empty((5,) + shape, order="F")
+    if strong:
+        rho = 0.2 + 2.0 * rng.random(shape)
+        u = 3.0 * (rng.random(shape) - 0.5)
+        v = 3.0 * (rng.random(shape) - 0.5)
+        p = 0.1 + 2.0 * rng.random(shape)
+    else:
+        rho = 1.0 + 0.1 * rng.random(shape)
+        u = 0.1 * rng.random(shape)
+        v = 0.05 * rng.random(shape)
+        p = 1.0 + 0.1 * rng.random(shape)
+    q[0] = rho
+    q[1] = rho * u
+    q[2] = rho * v
+    q[3] = p / 0.4 + 0.5 * rho * (u * u + v * v)
+    q[4] = rng.random(shape)
+    return q
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return O.RefEuler2D()
+
+
+@pytest.mark.parametrize("mx,my", [(5, 3), (40, 23), (97, 64)])
+@pytest.mark.parametrize("strong", [False, True])
+@pytest.mark.parametrize("order,mth", [(2, [4, 4, 4, 4, 2]), (2, [1, 2, 3, 5, 0]), (1, [4] * 5)])
+def test_step2ds_matches_reference(coracle, ref, mx, my, strong, order, mth):
+    rng = np.random.default_rng(mx * 1000 + my)
+    mbc = 2
+    q0 = euler_state(rng, (mx + 2 * mbc, my + 2 * mbc), strong)
+    par = [1.4, 0.4]
+    method = np.array([1, order, -1, 0, 0, 0, 0], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.1 / max(mx, my)
+    for ids in (1, 2):
+        a = q0.copy("F")
+        b = q0.copy("F")
+        _, ca = coracle.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), a, None, dx,
+                                dy, dt, method, mth, ids)
+        _, cb = ref.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), b, None, dx, dy,
+                            dt, method, mth, ids)
+        assert np.array_equal(a, b) and ca == cb
+
+
+@pytest.mark.parametrize("mx,my", [(6, 4), (33, 50)])
+@pytest.mark.parametrize("trans", [0, 1, 2])
+@pytest.mark.parametrize("strong", [False, True])
+def test_step2_unsplit_matches_reference(coracle, ref, mx, my, trans, strong):
+    rng = np.random.default_rng(mx + 7 * my + trans)
+    mbc = 2
+    q0 = euler_state(rng, (mx + 2 * mbc, my + 2 * mbc), strong)
+    par = [1.4, 0.4]
+    mth = [4, 4, 4, 4, 2]
+    method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.05 / max(mx, my)
+    a = q0.copy("F")
+    b = q0.copy("F")
+    _, ca = coracle.step2(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), a, None, dx, dy, dt,
+                          method, mth)
+    _, cb = ref.step2(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), b, None, dx, dy, dt,
+                      method, mth)
+    assert np.array_equal(a, b) and ca == cb
+
+
+@pytest.mark.parametrize("unsplit", [False, True])
+def test_capa_matches_reference(coracle, ref, unsplit):
+    rng = np.random.default_rng(3)
+    mx, my, mbc = 31, 18, 2
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    q0 = euler_state(rng, shape)
+    aux = np.asfortranarray(0.5 + rng.random((2,) + shape))
+    par = [1.4, 0.4]
+    mth = [4, 4, 4, 4, 2]
+    method = np.array([1, 2, 2 if unsplit else -1, 0, 0, 2, 2], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.03 / mx
+    a = q0.copy("F")
+    b = q0.copy("F")
+    if unsplit:
+        _, ca = coracle.step2(O.RP_EULER5_2D, par, mx, mbc, mx, my, q0.copy("F"), a, aux, dx, dy, dt, method, mth)
+        _, cb = ref.step2(O.RP_EULER5_2D, par, mx, mbc, mx, my, q0.copy("F"), b, aux, dx, dy, dt, method, mth)
+        assert np.array_equal(a, b) and ca == cb
+    else:
+        for ids in (1, 2):
+            _, ca = coracle.step2ds(O.RP_EULER5_2D, par, mx, mbc, mx, my, q0.copy("F"), a, aux, dx, dy, dt,
+                                    method, mth, ids)
+            _, cb = ref.step2ds(O.RP_EULER5_2D, par, mx, mbc, mx, my, q0.copy("F"), b, aux, dx, dy, dt,
+                                method, mth, ids)
+            assert np.array_equal(a, b) and ca == cb
