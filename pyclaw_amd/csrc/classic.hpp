@@ -101,10 +101,15 @@ __device__ __forceinline__ void cfl_publish(unsigned long long *word, double v) 
 // capa   : aux(mcapa) of this cell (CAPA only)
 // cfl_ok : interface l is one of i=1..mx+1 (counts for the Courant number)
 // returns the updated cell in qn; valid for lanes 2..61 when lanes l-2..l+2 hold real cells.
-template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1>
+//
+// TRANS (unsplit algorithm, flux2.f:151-189): instead of the updated cell, return the slice's
+// pieces for this cell -- qn := qadd, df := fadd(i+1)-fadd(i), g1/g2 := gadd(.,1,i), gadd(.,2,i)
+// (transverse flux corrections from rpt2 of amdq at interface i+1 and of apdq at interface i).
+template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = false>
 __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dtdx_c, double capa,
                                           bool cfl_ok, const SweepArgs &a,
-                                          double (&qn)[RP::MEQN], double &cflmax) {
+                                          double (&qn)[RP::MEQN], double &cflmax,
+                                          double *df = nullptr, double *g1 = nullptr, double *g2 = nullptr) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     using Cell = typename RP::Cell;
 
@@ -122,9 +127,9 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
             cflmax = dmax(dmax(cflmax, dtdx_c * s[mw]), -dtdx_l * s[mw]);
     }
 
-    double fadd[MEQN];
+    double fadd[MEQN], cq[MEQN];
 #pragma unroll
-    for (int m = 0; m < MEQN; m++) fadd[m] = 0.0;
+    for (int m = 0; m < MEQN; m++) { fadd[m] = 0.0; cq[m] = 0.0; }
 
     if (a.order != 1) {
         // limiter.f:33-57 -- dotl(i) = w(i-1).w(i) here, dotr(i) = dotl(i+1) from the right lane
@@ -175,8 +180,45 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                     c = first ? coef[mw] * wave[mw][m] : c + coef[mw] * wave[mw][m];
                     first = false;
                 }
+            cq[m] = c;
             fadd[m] = DIM1 ? c : 0.5 * c;
         }
+    }
+
+    if constexpr (TRANS) {
+        // Godunov increment and correction-flux difference of this cell (flux2.f:103-106,144)
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {
+            const double amdq_r = from_right(amdq[m]);
+            const double fadd_r = from_right(fadd[m]);
+            double qadd = -(dtdx_c * apdq[m]);
+            qn[m] = qadd - dtdx_c * amdq_r;
+            df[m] = fadd_r - fadd[m];
+            g1[m] = 0.0;
+            g2[m] = 0.0;
+        }
+        if (a.trans > 0) {
+            if (a.order > 1 && a.trans == 2) {  // flux2.f:153-159: split the correction waves too
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) { amdq[m] = amdq[m] + cq[m]; apdq[m] = apdq[m] - cq[m]; }
+            }
+            double bm[MEQN], bp[MEQN];
+            // B^-/B^+ A^- dq of interface l modify the cell to its LEFT (flux2.f:167-176)
+            RP::template transverse<IXY>(cL, cR, a.par, amdq, bm, bp);
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                g1[m] = -(0.5 * dtdx_c * from_right(bm[m]));
+                g2[m] = -(0.5 * dtdx_c * from_right(bp[m]));
+            }
+            // B^-/B^+ A^+ dq of interface l modify this cell (flux2.f:180-189)
+            RP::template transverse<IXY>(cL, cR, a.par, apdq, bm, bp);
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                g1[m] = g1[m] - 0.5 * dtdx_c * bm[m];
+                g2[m] = g2[m] - 0.5 * dtdx_c * bp[m];
+            }
+        }
+        return;
     }
 
     // update, step2ds.f:141-157 / step1.f:93-96,136-138
@@ -232,7 +274,7 @@ template <int IXY> struct TileShape {
 };
 constexpr int LINE = 16;  // doubles per 128-byte line
 
-template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1>
+template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = false>
 __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     using T = TileShape<IXY>;
     constexpr int MEQN = RP::MEQN;
@@ -296,7 +338,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     auto unit_al = [&](int u) { return (IXY == 1 ? u * STRIP : 0) + lane; };
     auto unit_live = [&](int u) {  // wave-uniform
         const int gb = b0 + unit_ac(u);
-        const bool across_ok = gb >= 0 && gb < n_across;
+        // step2ds sweeps every transverse index (ghost rows too, step2ds.f:83-88); the unsplit
+        // step2 only slices 0..m+1, i.e. one ghost layer (step2.f:84,164)
+        const int m_across = IXY == 1 ? a.my : a.mx;
+        const bool across_ok = TRANS ? (gb >= a.mbc - 1 && gb <= a.mbc + m_across) : (gb >= 0 && gb < n_across);
         const bool along_ok = a0 + (IXY == 1 ? u * STRIP : 0) + HALO < a.mbc + m_along;  // not all past the interior
         return u < T::UNITS && across_ok && along_ok;
     };
@@ -327,15 +372,48 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             if constexpr (CAPA) capanext = tile[T::at(MEQN, unit_al(u + 1), unit_ac(u + 1))];
         }
         if constexpr (CAPA) dtdx_c = DIM1 ? a.dt / (a.dx * capa) : a.dtd / capa;
-        if (a.ablate & 1) {
+        if constexpr (TRANS) {
+            // unsplit algorithm: this slice's pieces for the cell go to scratch planes; they are
+            // summed into qnew in the reference's order by combine_kernel (step2.f:130-137,214-218)
+            double df[MEQN], g1[MEQN], g2[MEQN];
+            lane_core<RP, IXY, CAPA, FWAVE, DIM1, true>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, df, g1, g2);
+            if (owned) {
+                const int gb = b0 + ac;
+                const long g = IXY == 1 ? (long)gb * a.pitch + ca : (long)ca * a.pitch + gb;
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) qn[m] = q[m];
-        } else
-            lane_core<RP, IXY, CAPA, FWAVE, DIM1>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax);
-        if (owned) {
+                for (int m = 0; m < MEQN; m++) {
+                    const long at = m * a.plane + g;
+                    const double fl = a.dtd * df[m];          // dtdx*(fadd(i+1)-fadd(i))
+                    const double gl = a.dtd_t * (g2[m] - g1[m]);  // dtdy*(gadd(2)-gadd(1))
+                    if (CAPA) {          // step2.f:145-148,227-230: qadd and (fl+gl), divided by capa later
+                        a.scr[0][at] = qn[m];
+                        a.scr[1][at] = fl + gl;
+                    } else if (IXY == 1) {  // step2.f:132-134: ((qnew+qadd) - fl) - gl
+                        a.scr[0][at] = qn[m];
+                        a.scr[1][at] = fl;
+                        a.scr[2][at] = gl;
+                    } else {               // step2.f:214-216: qnew + (qadd - fl - gl)
+                        a.scr[0][at] = qn[m] - fl - gl;
+                    }
+                    a.scr[3][at] = a.dtd_t * g1[m];
+                    a.scr[4][at] = a.dtd_t * g2[m];
+                }
+            }
+        } else {
+            if (a.ablate & 1) {
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = qn[m];
+                for (int m = 0; m < MEQN; m++) qn[m] = q[m];
+            } else
+                lane_core<RP, IXY, CAPA, FWAVE, DIM1>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax);
+            if (owned) {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = qn[m];
+            }
         }
+    }
+    if constexpr (TRANS) {
+        cfl_publish(a.cfl, cflmax);
+        return;
     }
     __syncthreads();
 
@@ -371,6 +449,48 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
         }
     }
     cfl_publish(a.cfl, cflmax);
+}
+
+// ---- unsplit algorithm: sum the slice pieces into qnew in the reference's order ----------------
+// step2.f runs the x slices j = 0..my+1 in ascending order, each adding into rows j-1, j, j+1,
+// then the y slices i = 0..mx+1 adding into columns i-1, i, i+1.  For interior cell (i,j) that is
+//   q1 = q0 + dtdy*gadd2 [slice j-1]            q4 = q3 + dtdx*gadd2 [slice i-1]
+//   q2 = ((q1 + qadd) - dtdx*df) - dtdy*dg [j]  q5 = q4 + (qadd - dtdy*df - dtdx*dg) [slice i]
+//   q3 = q2 - dtdy*gadd1 [slice j+1]            q6 = q5 - dtdx*gadd1 [slice i+1]
+// (with a capacity function every increment is divided by capa of the TARGET cell and the two
+// flux-difference terms are summed first, step2.f:145-152,227-234).  One thread per cell.
+template <bool CAPA>
+__global__ __launch_bounds__(256) void combine_kernel(CombineArgs c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= c.I) return;
+    const long g = (long)j * c.pitch + i;
+    if (i < c.mbc || i >= c.mbc + c.mx || j < c.mbc || j >= c.mbc + c.my) {  // ghost cells: unchanged
+        for (int m = 0; m < c.meqn; m++) c.qnew[m * c.plane + g] = c.qold[m * c.plane + g];
+        return;
+    }
+    double capa = 1.0;
+    if (CAPA) capa = c.aux[(long)(c.mcapa - 1) * c.plane + g];
+    for (int m = 0; m < c.meqn; m++) {
+        const long at = m * c.plane + g;
+        double q = c.qold[at];
+        if (CAPA) {
+            q = q + c.x[4][at - c.pitch] / capa;
+            q = q + c.x[0][at] - c.x[1][at] / capa;
+            q = q - c.x[3][at + c.pitch] / capa;
+            q = q + c.y[3][at - 1] / capa;
+            q = q + c.y[0][at] - c.y[1][at] / capa;
+            q = q - c.y[2][at + 1] / capa;
+        } else {
+            q = q + c.x[4][at - c.pitch];
+            q = q + c.x[0][at] - c.x[1][at] - c.x[2][at];
+            q = q - c.x[3][at + c.pitch];
+            q = q + c.y[3][at - 1];
+            q = q + c.y[0][at];
+            q = q - c.y[2][at + 1];
+        }
+        c.qnew[at] = q;
+    }
 }
 
 }  // namespace PCL_NS

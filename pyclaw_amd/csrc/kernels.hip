@@ -21,7 +21,7 @@ int hip_fail(std::string &err, const char *what, hipError_t e) {
     return PCL_EHIP;
 }
 
-template <class RP, int IXY, bool DIM1> int launch(const SweepLaunch &l, std::string &err) {
+template <class RP, int IXY, bool DIM1, bool TRANS = false> int launch(const SweepLaunch &l, std::string &err) {
     using T = TileShape<IXY>;
     const SweepArgs &a = l.a;
     const int n_across = IXY == 1 ? a.J : a.I + (LINE - a.mbc);  // y: columns counted from the line boundary
@@ -30,10 +30,10 @@ template <class RP, int IXY, bool DIM1> int launch(const SweepLaunch &l, std::st
     const int ntiles_along = (m_along + T::NSTRIP * STRIP - 1) / (T::NSTRIP * STRIP);
     const dim3 grid((unsigned)ntiles_across * (unsigned)ntiles_along);
     if (a.mcapa > 0)
-        hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, false, DIM1>), grid, dim3(256), 0, l.stream, a,
+        hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, false, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
                            ntiles_across, ntiles_along);
     else
-        hipLaunchKernelGGL((sweep_kernel<RP, IXY, false, false, DIM1>), grid, dim3(256), 0, l.stream, a,
+        hipLaunchKernelGGL((sweep_kernel<RP, IXY, false, false, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
                            ntiles_across, ntiles_along);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep launch", e);
@@ -60,6 +60,31 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
     }
     err = "Riemann solver id is not a 2-D solver";
     return PCL_EINVAL;
+}
+
+// unsplit (step2.f): per-slice pieces of one direction into the scratch planes
+int launch_slices(const SweepLaunch &l, std::string &err) {
+    if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
+    if (l.ndim != 2) { err = "step2 is 2-D"; return PCL_EINVAL; }
+    if (l.ids == 1) {
+        if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false, true>(l, err);
+        if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false, true>(l, err);
+    } else {
+        if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false, true>(l, err);
+        if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false, true>(l, err);
+    }
+    err = "Riemann solver id is not a 2-D solver";
+    return PCL_EINVAL;
+}
+
+int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err) {
+    const dim3 grid((unsigned)((c.I + 255) / 256), (unsigned)c.J);
+    if (c.mcapa > 0)
+        hipLaunchKernelGGL(combine_kernel<true>, grid, dim3(256), 0, stream, c);
+    else
+        hipLaunchKernelGGL(combine_kernel<false>, grid, dim3(256), 0, stream, c);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "combine launch", e);
 }
 
 #if !PCL_FAST

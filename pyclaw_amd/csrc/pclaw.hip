@@ -39,6 +39,7 @@ struct pcl_solver {
                           // cell of every row starts a 128-byte line (16 - mbc)
     double *q = nullptr, *t1 = nullptr, *t2 = nullptr, *bak = nullptr;
     double *aux = nullptr;
+    double *scr[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // unsplit slice pieces
     double *stage = nullptr;  // AoS staging for host transfers (qbc-sized)
     size_t stage_bytes = 0;
     unsigned long long *cfl_dev = nullptr;
@@ -229,6 +230,47 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt)
     return rc;
 }
 
+// unsplit step (step2.f): x slices and y slices of qold into scratch planes, then one combine pass
+int do_unsplit(pcl_solver *s, double dt) {
+    const size_t qbytes = ((size_t)s->total + 16) * sizeof(double);
+    for (int k = 0; k < 9; k++) {
+        if (s->scr[k]) continue;
+        double *raw = nullptr;
+        HIP_TRY(hipMalloc((void **)&raw, qbytes));
+        HIP_TRY(hipMemsetAsync(raw, 0, qbytes, s->stream));
+        s->scr[k] = raw + s->lead;
+    }
+    std::string err;
+    for (int ids = 1; ids <= 2; ids++) {
+        SweepLaunch l;
+        l.a = make_args(s, s->q, nullptr, ids, dt);
+        l.a.trans = s->cfg.method[2];
+        l.a.dtd_t = dt / s->cfg.d[2 - ids];
+        if (ids == 1) {
+            for (int k = 0; k < 5; k++) l.a.scr[k] = s->scr[k];
+        } else {  // the y slices never write slot 2 (step2.f:214-216 keeps one parenthesised term)
+            l.a.scr[0] = s->scr[5]; l.a.scr[1] = s->scr[6]; l.a.scr[2] = nullptr;
+            l.a.scr[3] = s->scr[7]; l.a.scr[4] = s->scr[8];
+        }
+        l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = s->stream;
+        pcl_solver::Timed t{};
+        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; hipEventRecord(t.a, s->stream); }
+        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_slices(l, err) : pcl::exact::launch_slices(l, err);
+        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
+        if (rc) return fail(rc, err);
+    }
+    CombineArgs c;
+    c.qold = s->q; c.qnew = s->t1; c.aux = s->aux;
+    for (int k = 0; k < 5; k++) c.x[k] = s->scr[k];
+    c.y[0] = s->scr[5]; c.y[1] = s->scr[6]; c.y[2] = s->scr[7]; c.y[3] = s->scr[8];
+    c.pitch = s->pitch; c.plane = s->plane; c.I = s->I; c.J = s->J; c.mbc = s->cfg.mbc;
+    c.mx = s->cfg.n[0]; c.my = s->cfg.n[1]; c.mcapa = s->cfg.method[5]; c.meqn = s->cfg.meqn;
+    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_combine(c, s->stream, err)
+                                          : pcl::exact::launch_combine(c, s->stream, err);
+    if (rc) return fail(rc, err);
+    return PCL_OK;
+}
+
 int read_cfl(pcl_solver *s, double *cfl) {
     HIP_TRY(hipMemcpyAsync(s->cfl_host, s->cfl_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            s->stream));
@@ -331,6 +373,8 @@ void pcl_destroy(pcl_solver *s) {
     for (auto &t : s->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto &e : s->evpool) hipEventDestroy(e);
     for (double *p : {s->q, s->t1, s->t2, s->bak, s->aux, s->stage})
+        if (p) hipFree(p - s->lead);
+    for (double *p : s->scr)
         if (p) hipFree(p - s->lead);
     hipFree(s->cfl_dev);
     if (s->cfl_host) hipHostFree(s->cfl_host);
@@ -484,8 +528,10 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
         if (int rc = do_sweep(s, s->t1, s->t2, 2, dt)) return rc;
         std::swap(s->q, s->t2);
         s->undo_slot = &s->t2;
-    } else {
-        return fail(PCL_EINVAL, "unsplit step2 (dim_split=False) is not implemented yet");
+    } else {  // unsplit, clawpack.py:550-552 -> step2.f
+        if (int rc = do_unsplit(s, dt)) return rc;
+        std::swap(s->q, s->t1);
+        s->undo_slot = &s->t1;
     }
     return read_cfl(s, cfl);
 }

@@ -28,6 +28,21 @@ struct SweepArgs {
     RpParams par;
     unsigned long long *cfl;  // device word holding the running max (as ordered bits)
     int ablate;       // diagnostic only (tools/kbench.py): bit0 = skip the arithmetic (copy through)
+    // unsplit algorithm (step2.f) only:
+    int trans;        // method(3): 0 no transverse terms, 1 increment waves, 2 + correction waves
+    double dtd_t;     // dt/d of the transverse direction
+    double *scr[5];   // per-slice pieces, combined in the reference's order by combine_kernel
+};
+
+// Pointers for the unsplit combine pass (step2.f:130-137,214-218 accumulation order)
+struct CombineArgs {
+    const double *qold;
+    double *qnew;
+    const double *aux;
+    const double *x[5];  // x slices: qadd, dtdx*df (or S with capa), dtdy*dg, dtdy*gadd1, dtdy*gadd2
+    const double *y[4];  // y slices: mid (or qadd with capa), S (capa only), dtdx*gadd1, dtdx*gadd2
+    long pitch, plane;
+    int I, J, mbc, mx, my, mcapa, meqn;
 };
 
 struct SweepLaunch {
@@ -40,7 +55,15 @@ struct SweepLaunch {
 };
 
 // defined in kernels.hip, once per arithmetic mode; returns 0 or a PCL_E* code + message
-namespace exact { int launch_sweep(const SweepLaunch &l, std::string &err); }
-namespace fast { int launch_sweep(const SweepLaunch &l, std::string &err); }
+namespace exact {
+int launch_sweep(const SweepLaunch &l, std::string &err);
+int launch_slices(const SweepLaunch &l, std::string &err);   // unsplit: per-slice pieces -> scratch
+int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
+}
+namespace fast {
+int launch_sweep(const SweepLaunch &l, std::string &err);
+int launch_slices(const SweepLaunch &l, std::string &err);
+int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
+}
 
 }  // namespace pcl

@@ -159,3 +159,76 @@ def test_step1_bitexact(coracle, rp, meqn, mwaves, par, mx, lim):
     # interior cells only: the Fortran also dirties ghost cells 0 and mx+1, which nobody reads
     assert np.array_equal(out[:, mbc:-mbc], ref[:, mbc:-mbc]), np.abs(out - ref)[:, mbc:-mbc].max()
     assert cfl.value == cfl_ref
+
+
+@pytest.mark.parametrize("mx,my", [(1, 1), (6, 4), (61, 59), (130, 75), (250, 97)])
+@pytest.mark.parametrize("trans", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["smooth", "transonic"])
+def test_step2_unsplit_euler_bitexact(coracle, mx, my, trans, kind):
+    """pcl_step2 (unsplit, transverse Riemann solves) == oracle step2 (== reference step2.f, see
+    tests/test_oracle_vs_ref.py), interior cells, bit for bit."""
+    L = _lib()
+    rng = np.random.default_rng(31 * mx + my + trans)
+    mbc = 2
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    q0 = euler_state(rng, shape) if kind == "smooth" else euler_transonic_state(rng, shape)
+    par = np.array([1.4, 0.4])
+    mth = np.array([4, 4, 4, 4, 2], dtype=np.int32)
+    method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 0.7 / my, 0.05 / max(mx, my)
+    ref = q0.copy("F")
+    _, cfl_ref = coracle.step2(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), ref, None, dx, dy,
+                               dt, method, mth)
+    out = q0.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 0, mbc, mx, my, L.d(q0), L.d(out), None, dx,
+                              dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
+    assert np.array_equal(out[inner], ref[inner]), "max diff %g" % np.abs(out[inner] - ref[inner]).max()
+    assert cfl.value == cfl_ref
+
+
+@pytest.mark.parametrize("trans", [1, 2])
+@pytest.mark.parametrize("order", [1, 2])
+def test_step2_unsplit_acoustics_bitexact(coracle, trans, order):
+    """restated rpt2_acoustics (no reference golden: parity unpinned at the solver boundary)"""
+    L = _lib()
+    rng = np.random.default_rng(9)
+    mx, my, mbc = 70, 41, 2
+    q0 = np.asfortranarray(rng.standard_normal((3, mx + 2 * mbc, my + 2 * mbc)))
+    par = np.array([1.0, 4.0, 2.0, 2.0])
+    mth = np.array([4, 4], dtype=np.int32)
+    method = np.array([1, order, trans, 0, 0, 0, 0], dtype=np.int32)
+    dx, dy, dt = 2.0 / mx, 2.0 / my, 0.2 / max(mx, my)
+    ref = q0.copy("F")
+    _, cfl_ref = coracle.step2(O.RP_ACOUSTICS_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), ref, None, dx,
+                               dy, dt, method, mth)
+    out = q0.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2(O.RP_ACOUSTICS_2D, L.d(par), 0, 3, 2, 0, mbc, mx, my, L.d(q0), L.d(out), None,
+                              dx, dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
+    assert np.array_equal(out[inner], ref[inner]), np.abs(out[inner] - ref[inner]).max()
+    assert cfl.value == cfl_ref
+
+
+def test_step2_unsplit_capa_bitexact(coracle):
+    L = _lib()
+    rng = np.random.default_rng(12)
+    mx, my, mbc = 64, 30, 2
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    q0 = euler_state(rng, shape)
+    aux = np.asfortranarray(0.5 + rng.random((2,) + shape))
+    par = np.array([1.4, 0.4])
+    mth = np.array([4, 4, 4, 4, 2], dtype=np.int32)
+    method = np.array([1, 2, 2, 0, 0, 1, 2], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.03 / mx
+    ref = q0.copy("F")
+    _, cfl_ref = coracle.step2(O.RP_EULER5_2D, par, mx, mbc, mx, my, q0.copy("F"), ref, aux, dx, dy, dt, method, mth)
+    out = q0.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 2, mbc, mx, my, L.d(q0), L.d(out), L.d(aux), dx,
+                              dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
+    assert np.array_equal(out[inner], ref[inner]), np.abs(out[inner] - ref[inner]).max()
+    assert cfl.value == cfl_ref
