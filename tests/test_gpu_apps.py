@@ -99,3 +99,46 @@ def test_acoustics2d_fast(coracle):
     q = claw.frames[claw.nout].state.q
     scale = np.abs(p.q).max()
     assert np.max(np.abs(q - p.q)) < RTOL * scale
+
+
+def test_shockbubble_unsplit_app_config(coracle):
+    """apps/euler/2d/shockbubble/shockbubble.py:180-181 runs the UNSPLIT algorithm with
+    order_trans=2 (no golden in the reference for it): replay against the oracle driver."""
+    import pyclaw_amd as pyclaw
+    claw = problems.shockbubble(pyclaw, mx=80, my=20, tfinal=0.05, dim_split=False, order_trans=2)
+    p = D.shockbubble_problem(mx=80, my=20, dim_split=False, order_trans=2)
+    st = D.run(p, coracle, 0.05, 1)[-1]
+    assert claw.solver.status['numsteps'] == st['numsteps']
+    assert np.array_equal(claw.frames[1].state.q, p.q)
+
+
+def test_acoustics2d_unsplit_reflecting(coracle):
+    """apps/acoustics/2d/homogeneous/acoustics.py:21,31-53: unsplit, reflecting/outflow walls."""
+    import pyclaw_amd as pyclaw
+    claw = problems.acoustics2D(pyclaw, mx=60, my=50, tfinal=0.1, nout=2, dim_split=0, run=False)
+    s = claw.solver
+    s.order_trans = 2
+    s.bc_lower[0] = pyclaw.BC.reflecting
+    s.bc_lower[1] = pyclaw.BC.reflecting
+    claw.run()
+    p = D.acoustics2d_problem(mx=60, my=50, dim_split=False, order_trans=2,
+                              bcs=([D.REFLECTING, D.REFLECTING], [D.OUTFLOW, D.OUTFLOW]))
+    D.run(p, coracle, 0.1, 2)
+    assert np.array_equal(claw.frames[2].state.q, p.q)
+
+
+def test_strang_source_and_start_step(coracle):
+    """src_split=2 (Strang) + a start_step hook: exercises the copied device backup path
+    (solver.py:660,690) through a rejected step."""
+    import pyclaw_amd as pyclaw
+    calls = []
+    claw = problems.shockbubble(pyclaw, mx=40, my=10, tfinal=0.02, run=False, dt_initial=0.05)
+    claw.solver.src_split = 2
+    claw.solver.start_step = lambda solver, solution: calls.append(solution.t)
+    claw.run()
+    p = D.shockbubble_problem(mx=40, my=10, dt_initial=0.05)
+    p.src_split = 2
+    st = D.run(p, coracle, 0.02, 1)[-1]
+    assert claw.solver.status['numsteps'] == st['numsteps'] and p.nrejected >= 1
+    assert len(calls) == st['numsteps'] + p.nrejected
+    assert np.array_equal(claw.frames[1].state.q, p.q)
