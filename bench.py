@@ -44,6 +44,24 @@ def build(nx_global, ny_global, math):
     return claw
 
 
+def pmc_traffic(math, which, nx, ny):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_final_pmc_hbm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
+    passes, same bench command).  PMC counters cannot be read from inside this process, so the
+    number is only reported for the configuration it was collected on (4096 x 4096)."""
+    if (nx, ny) != (4096, 4096):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.json")) as f:
+            modes = json.load(f)["modes"][math]
+        for name, v in modes.items():
+            if ("Euler5, %d," % (which + 1)) in name:
+                return v["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(nx, ny, max_seconds=30.0):
     """Time the reference's CPU path on ONE core on a bounded sample of the same workload:
     whole dim-split steps (x then y sweep) of the same Euler state on an nx x (rows) slab.
@@ -136,7 +154,8 @@ def main():
     value = cells_total * args.steps / elapsed / 1e6
 
     if rank == 0:
-        names = ["sweep_x_kernel<Euler5>", "sweep_y_kernel<Euler5>"]
+        ns = "pcl::%s::" % args.math
+        names = [ns + "sweep_kernel<Euler5, 1> (x pass)", ns + "sweep_kernel<Euler5, 2> (y pass)"]
         avg = [ms[k] / max(1, nl[k]) for k in range(2)]
         dom = int(np.argmax(avg))
         bytes_launch = BYTES_PER_CELL_SWEEP * float(args.nx) * float(args.ny)
@@ -154,7 +173,8 @@ def main():
                        "launches": {names[0]: int(nl[0]), names[1]: int(nl[1])},
                        "steps_incl_rejected": int(nl[0]), "result_finite": finite},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.math, dom, args.nx, args.ny),
                          "avg_ms": {names[0]: avg[0], names[1]: avg[1]},
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
