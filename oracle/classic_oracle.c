@@ -97,13 +97,13 @@ static void limiter(int meqn, int mwaves, int mbc, int mx, double *wave,
 
 /* ------------------------------------------------------- Riemann solvers */
 /* 1-D, restated (third-party rp1_advection.f): wave = dq, s = u */
-static void rp1_advection(int meqn, int mwaves, int mbc, int mx, const double *q,
+static void rp1_advection(int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
                           double *wave, double *s, double *amdq, double *apdq,
                           const double *par)
 {
     double u = par[0];
     for (int i = 2 - mbc; i <= mx + mbc; i++) {
-        W(1, 1, i) = A2(q, 1, i) - A2(q, 1, i - 1);
+        W(1, 1, i) = A2(ql, 1, i) - A2(qr, 1, i - 1);
         S(1, i) = u;
         A2(amdq, 1, i) = dmin(u, 0.0) * W(1, 1, i);
         A2(apdq, 1, i) = dmax(u, 0.0) * W(1, 1, i);
@@ -111,14 +111,14 @@ static void rp1_advection(int meqn, int mwaves, int mbc, int mx, const double *q
 }
 
 /* 1-D acoustics, restated (third-party rp1_acoustics.f); par = rho,bulk,cc,zz */
-static void rp1_acoustics(int meqn, int mwaves, int mbc, int mx, const double *q,
+static void rp1_acoustics(int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
                           double *wave, double *s, double *amdq, double *apdq,
                           const double *par)
 {
     double cc = par[2], zz = par[3];
     for (int i = 2 - mbc; i <= mx + mbc; i++) {
-        double d1 = A2(q, 1, i) - A2(q, 1, i - 1);
-        double d2 = A2(q, 2, i) - A2(q, 2, i - 1);
+        double d1 = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        double d2 = A2(ql, 2, i) - A2(qr, 2, i - 1);
         double a1 = (-d1 + zz * d2) / (2.0 * zz);
         double a2 = (d1 + zz * d2) / (2.0 * zz);
         W(1, 1, i) = -a1 * zz;
@@ -136,14 +136,14 @@ static void rp1_acoustics(int meqn, int mwaves, int mbc, int mx, const double *q
 
 /* 2-D acoustics normal solver, restated (third-party rpn2_acoustics.f) */
 static void rpn2_acoustics(int ixy, int meqn, int mwaves, int mbc, int mx,
-                           const double *q, double *wave, double *s, double *amdq,
+                           const double *ql, const double *qr, double *wave, double *s, double *amdq,
                            double *apdq, const double *par)
 {
     double cc = par[2], zz = par[3];
     int mu = (ixy == 1) ? 2 : 3, mv = (ixy == 1) ? 3 : 2;
     for (int i = 2 - mbc; i <= mx + mbc; i++) {
-        double d1 = A2(q, 1, i) - A2(q, 1, i - 1);
-        double d2 = A2(q, mu, i) - A2(q, mu, i - 1);
+        double d1 = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        double d2 = A2(ql, mu, i) - A2(qr, mu, i - 1);
         double a1 = (-d1 + zz * d2) / (2.0 * zz);
         double a2 = (d1 + zz * d2) / (2.0 * zz);
         W(1, 1, i) = -a1 * zz;
@@ -183,22 +183,22 @@ static void rpt2_acoustics(int ixy, int meqn, int mbc, int mx, const double *asd
 /* Roe averages of one Euler interface; rpn2_euler_5wave.f:87-104 */
 typedef struct { double u, v, enth, a, g1a2, euv, u2v2; } roe_t;
 
-static inline roe_t euler_roe(const double *q, int meqn, int mbc, int i, int mu,
+static inline roe_t euler_roe(const double *ql, const double *qr, int meqn, int mbc, int i, int mu,
                               int mv, double gamma1)
 {
     roe_t r;
-    double rhsqrtl = sqrt(A2(q, 1, i - 1));
-    double rhsqrtr = sqrt(A2(q, 1, i));
-    double pl = gamma1 * (A2(q, 4, i - 1) -
-                          0.5 * (A2(q, 2, i - 1) * A2(q, 2, i - 1) +
-                                 A2(q, 3, i - 1) * A2(q, 3, i - 1)) / A2(q, 1, i - 1));
-    double pr = gamma1 * (A2(q, 4, i) -
-                          0.5 * (A2(q, 2, i) * A2(q, 2, i) + A2(q, 3, i) * A2(q, 3, i)) /
-                              A2(q, 1, i));
+    double rhsqrtl = sqrt(A2(qr, 1, i - 1));
+    double rhsqrtr = sqrt(A2(ql, 1, i));
+    double pl = gamma1 * (A2(qr, 4, i - 1) -
+                          0.5 * (A2(qr, 2, i - 1) * A2(qr, 2, i - 1) +
+                                 A2(qr, 3, i - 1) * A2(qr, 3, i - 1)) / A2(qr, 1, i - 1));
+    double pr = gamma1 * (A2(ql, 4, i) -
+                          0.5 * (A2(ql, 2, i) * A2(ql, 2, i) + A2(ql, 3, i) * A2(ql, 3, i)) /
+                              A2(ql, 1, i));
     double rhsq2 = rhsqrtl + rhsqrtr;
-    r.u = (A2(q, mu, i - 1) / rhsqrtl + A2(q, mu, i) / rhsqrtr) / rhsq2;
-    r.v = (A2(q, mv, i - 1) / rhsqrtl + A2(q, mv, i) / rhsqrtr) / rhsq2;
-    r.enth = (((A2(q, 4, i - 1) + pl) / rhsqrtl + (A2(q, 4, i) + pr) / rhsqrtr)) / rhsq2;
+    r.u = (A2(qr, mu, i - 1) / rhsqrtl + A2(ql, mu, i) / rhsqrtr) / rhsq2;
+    r.v = (A2(qr, mv, i - 1) / rhsqrtl + A2(ql, mv, i) / rhsqrtr) / rhsq2;
+    r.enth = (((A2(qr, 4, i - 1) + pl) / rhsqrtl + (A2(ql, 4, i) + pr) / rhsqrtr)) / rhsq2;
     r.u2v2 = r.u * r.u + r.v * r.v;
     double a2 = gamma1 * (r.enth - .5 * r.u2v2);
     r.a = sqrt(a2);
@@ -208,19 +208,19 @@ static inline roe_t euler_roe(const double *q, int meqn, int mbc, int i, int mu,
 }
 
 /* rpn2_euler_5wave.f:5-302, efix = .true.; par = gamma, gamma1 */
-static void rpn2_euler5(int ixy, int meqn, int mwaves, int mbc, int mx, const double *q,
+static void rpn2_euler5(int ixy, int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
                         double *wave, double *s, double *amdq, double *apdq,
                         const double *par)
 {
     double gamma = par[0], gamma1 = par[1];
     int mu = (ixy == 1) ? 2 : 3, mv = (ixy == 1) ? 3 : 2;
     for (int i = 2 - mbc; i <= mx + mbc; i++) {
-        roe_t r = euler_roe(q, meqn, mbc, i, mu, mv, gamma1);
+        roe_t r = euler_roe(ql, qr, meqn, mbc, i, mu, mv, gamma1);
         double u = r.u, v = r.v, enth = r.enth, a = r.a;
-        double delta1 = A2(q, 1, i) - A2(q, 1, i - 1);
-        double delta2 = A2(q, mu, i) - A2(q, mu, i - 1);
-        double delta3 = A2(q, mv, i) - A2(q, mv, i - 1);
-        double delta4 = A2(q, 4, i) - A2(q, 4, i - 1);
+        double delta1 = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        double delta2 = A2(ql, mu, i) - A2(qr, mu, i - 1);
+        double delta3 = A2(ql, mv, i) - A2(qr, mv, i - 1);
+        double delta4 = A2(ql, 4, i) - A2(qr, 4, i - 1);
         double a3 = r.g1a2 * (r.euv * delta1 + u * delta2 + v * delta3 - delta4);
         double a2 = delta3 - v * delta1;
         double a4 = (delta2 + (a - u) * delta1 - a * a3) / (2.0 * a);
@@ -258,27 +258,27 @@ static void rpn2_euler5(int ixy, int meqn, int mwaves, int mbc, int mx, const do
         W(mu, 5, i) = 0.0;
         W(mv, 5, i) = 0.0;
         W(4, 5, i) = 0.0;
-        W(5, 5, i) = A2(q, 5, i) - A2(q, 5, i - 1);
+        W(5, 5, i) = A2(ql, 5, i) - A2(qr, 5, i - 1);
         S(5, i) = u;
     }
 
     /* entropy fix, rpn2_euler_5wave.f:205-286 */
     for (int i = 2 - mbc; i <= mx + mbc; i++) {
-        double rhoim1 = A2(q, 1, i - 1);
-        double pim1 = gamma1 * (A2(q, 4, i - 1) -
-                                0.5 * (A2(q, mu, i - 1) * A2(q, mu, i - 1) +
-                                       A2(q, mv, i - 1) * A2(q, mv, i - 1)) / rhoim1);
+        double rhoim1 = A2(qr, 1, i - 1);
+        double pim1 = gamma1 * (A2(qr, 4, i - 1) -
+                                0.5 * (A2(qr, mu, i - 1) * A2(qr, mu, i - 1) +
+                                       A2(qr, mv, i - 1) * A2(qr, mv, i - 1)) / rhoim1);
         double cim1 = sqrt(gamma * pim1 / rhoim1);
-        double s0 = A2(q, mu, i - 1) / rhoim1 - cim1;
+        double s0 = A2(qr, mu, i - 1) / rhoim1 - cim1;
 
         if (s0 >= 0.0 && S(1, i) > 0.0) {
             for (int m = 1; m <= meqn; m++) A2(amdq, m, i) = 0.0;
             continue;
         }
-        double rho1 = A2(q, 1, i - 1) + W(1, 1, i);
-        double rhou1 = A2(q, mu, i - 1) + W(mu, 1, i);
-        double rhov1 = A2(q, mv, i - 1) + W(mv, 1, i);
-        double en1 = A2(q, 4, i - 1) + W(4, 1, i);
+        double rho1 = A2(qr, 1, i - 1) + W(1, 1, i);
+        double rhou1 = A2(qr, mu, i - 1) + W(mu, 1, i);
+        double rhov1 = A2(qr, mv, i - 1) + W(mv, 1, i);
+        double en1 = A2(qr, 4, i - 1) + W(4, 1, i);
         double p1 = gamma1 * (en1 - 0.5 * (rhou1 * rhou1 + rhov1 * rhov1) / rho1);
         double c1 = sqrt(gamma * p1 / rho1);
         double s1 = rhou1 / rho1 - c1;
@@ -298,17 +298,17 @@ static void rpn2_euler5(int ixy, int meqn, int mwaves, int mbc, int mx, const do
             A2(amdq, m, i) = A2(amdq, m, i) + S(5, i) * W(m, 5, i);
         }
 
-        double rhoi = A2(q, 1, i);
-        double pi = gamma1 * (A2(q, 4, i) -
-                              0.5 * (A2(q, mu, i) * A2(q, mu, i) +
-                                     A2(q, mv, i) * A2(q, mv, i)) / rhoi);
+        double rhoi = A2(ql, 1, i);
+        double pi = gamma1 * (A2(ql, 4, i) -
+                              0.5 * (A2(ql, mu, i) * A2(ql, mu, i) +
+                                     A2(ql, mv, i) * A2(ql, mv, i)) / rhoi);
         double ci = sqrt(gamma * pi / rhoi);
-        double s3 = A2(q, mu, i) / rhoi + ci;
+        double s3 = A2(ql, mu, i) / rhoi + ci;
 
-        double rho2 = A2(q, 1, i) - W(1, 4, i);
-        double rhou2 = A2(q, mu, i) - W(mu, 4, i);
-        double rhov2 = A2(q, mv, i) - W(mv, 4, i);
-        double en2 = A2(q, 4, i) - W(4, 4, i);
+        double rho2 = A2(ql, 1, i) - W(1, 4, i);
+        double rhou2 = A2(ql, mu, i) - W(mu, 4, i);
+        double rhov2 = A2(ql, mv, i) - W(mv, 4, i);
+        double en2 = A2(ql, 4, i) - W(4, 4, i);
         double p2 = gamma1 * (en2 - 0.5 * (rhou2 * rhou2 + rhov2 * rhov2) / rho2);
         double c2 = sqrt(gamma * p2 / rho2);
         double s2 = rhou2 / rho2 + c2;
@@ -338,7 +338,7 @@ static void rpt2_euler5(int ixy, int meqn, int mbc, int mx, const double *q,
     double gamma1 = par[1];
     int mu = (ixy == 1) ? 2 : 3, mv = (ixy == 1) ? 3 : 2;
     for (int i = 2 - mbc; i <= mx + mbc; i++) {
-        roe_t r = euler_roe(q, meqn, mbc, i, mu, mv, gamma1);
+        roe_t r = euler_roe(q, q, meqn, mbc, i, mu, mv, gamma1);
         double u = r.u, v = r.v, enth = r.enth, a = r.a;
         double a3 = r.g1a2 * (r.euv * A2(asdq, 1, i) + u * A2(asdq, mu, i) +
                               v * A2(asdq, mv, i) - A2(asdq, 4, i));
@@ -385,15 +385,15 @@ static void rpt2_euler5(int ixy, int meqn, int mbc, int mx, const double *q,
 }
 
 static int rpn2_dispatch(int rp, int ixy, int meqn, int mwaves, int mbc, int mx,
-                         const double *q, double *wave, double *s, double *amdq,
+                         const double *ql, const double *qr, double *wave, double *s, double *amdq,
                          double *apdq, const double *par)
 {
     switch (rp) {
     case RP_ACOUSTICS_2D:
-        rpn2_acoustics(ixy, meqn, mwaves, mbc, mx, q, wave, s, amdq, apdq, par);
+        rpn2_acoustics(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
     case RP_EULER5_2D:
-        rpn2_euler5(ixy, meqn, mwaves, mbc, mx, q, wave, s, amdq, apdq, par);
+        rpn2_euler5(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
     }
     return -1;
@@ -468,7 +468,7 @@ static int flux2(int rp, const double *par, int fwave, int ixy, int meqn, int mw
             GADD(m, 2, i) = 0.0;
         }
 
-    if (rpn2_dispatch(rp, ixy, meqn, mwaves, mbc, mx, q1d, wave, s, amdq, apdq, par))
+    if (rpn2_dispatch(rp, ixy, meqn, mwaves, mbc, mx, q1d, q1d, wave, s, amdq, apdq, par))
         return -1;
 
     /* forall semantics (flux2.f:103-106): all apdq updates, then all amdq updates */
@@ -718,8 +718,8 @@ int orc_step1(int rp, const double *par, int meqn, int mwaves, int maux, int mbc
             DT(i) = dt / dx;
     }
     switch (rp) {
-    case RP_ADVECTION_1D: rp1_advection(meqn, mwaves, mbc, mx, q, wave, s, amdq, apdq, par); break;
-    case RP_ACOUSTICS_1D: rp1_acoustics(meqn, mwaves, mbc, mx, q, wave, s, amdq, apdq, par); break;
+    case RP_ADVECTION_1D: rp1_advection(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
+    case RP_ACOUSTICS_1D: rp1_acoustics(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
     default: rc = -1;
     }
     if (!rc) {
@@ -758,7 +758,24 @@ int orc_step1(int rp, const double *par, int meqn, int mwaves, int maux, int mbc
 int orc_rpn2(int rp, const double *par, int ixy, int meqn, int mwaves, int mbc, int mx,
              const double *q1d, double *wave, double *s, double *amdq, double *apdq)
 {
-    return rpn2_dispatch(rp, ixy, meqn, mwaves, mbc, mx, q1d, wave, s, amdq, apdq, par);
+    return rpn2_dispatch(rp, ixy, meqn, mwaves, mbc, mx, q1d, q1d, wave, s, amdq, apdq, par);
+}
+
+/* separate edge states (SharpClaw: ql/qr from the reconstruction) */
+int orc_rpn2_ptr(int rp, const double *par, int ixy, int meqn, int mwaves, int mbc, int mx,
+                 const double *ql, const double *qr, double *wave, double *s, double *amdq, double *apdq)
+{
+    return rpn2_dispatch(rp, ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
+}
+
+int orc_rp1_ptr(int rp, const double *par, int meqn, int mwaves, int mbc, int mx, const double *ql,
+                const double *qr, double *wave, double *s, double *amdq, double *apdq)
+{
+    switch (rp) {
+    case RP_ADVECTION_1D: rp1_advection(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
+    case RP_ACOUSTICS_1D: rp1_acoustics(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
+    }
+    return -1;
 }
 
 int orc_rpt2(int rp, const double *par, int ixy, int meqn, int mbc, int mx,

@@ -99,13 +99,19 @@ class Problem:
         self.user_bc_upper = None
         self.aux_bc_lower = None
         self.aux_bc_upper = None
+        self.solver_type = 'classic'
+        self.lim_type = 2
+        self.time_integrator = 'SSP104'
         self.__dict__.update(kw)
+        if self.solver_type == 'sharpclaw' and 'mbc' not in kw:
+            self.mbc = 3                                   # (weno_order+1)/2, sharpclaw.py:479
         self.ndim = self.q.ndim - 1
         self.t = 0.0
         self.dt = self.dt_initial
         # solver.py:172: CFL(_default_attr_values['cfl_desired']) -- the CLASS default (0.9 for
-        # ClawSolver, clawpack.py:108), not the user's cfl_desired; it seeds status['cflmax'].
-        self.cfl = 0.9
+        # ClawSolver, clawpack.py:108; 2.45 for SharpClawSolver, sharpclaw.py:144), not the user's
+        # cfl_desired; it seeds status['cflmax'].
+        self.cfl = 2.45 if self.solver_type == 'sharpclaw' else 0.9
         self.nrejected = 0
         self.dt_history = []
 
@@ -199,7 +205,10 @@ def evolve_to_time(p, backend, tend):
         if p.dt_variable:
             q_backup = p.q.copy("F")
             told = p.t
-        step(p, backend)
+        if getattr(p, 'solver_type', 'classic') == 'sharpclaw':
+            sharp_step(p, backend)
+        else:
+            step(p, backend)
         cfl = p.cfl
         p.dt_history.append((p.dt, cfl))
         if cfl <= p.cfl_max:
@@ -229,6 +238,61 @@ def evolve_to_time(p, backend, tend):
     if p.dt_variable and p.t < tend and status["numsteps"] == max_steps:
         raise Exception("Maximum number of timesteps have been taken")
     return status
+
+
+# ---------------------------------------------------------------------------------
+# SharpClaw: method-of-lines step (src/pyclaw/sharpclaw.py:152-237, 515-563)
+# ---------------------------------------------------------------------------------
+class CFLError(Exception):
+    pass
+
+
+def sharp_dq(p, backend, q, t):
+    """SharpClawSolver.dq -> dq_hyperbolic on an interior array q (a stage register)."""
+    mbc = p.mbc
+    inner = (slice(None),) + (slice(mbc, -mbc),) * p.ndim
+    p.qbc[inner] = q
+    fill_ghosts(p.qbc, mbc, p.bc_lower, p.bc_upper, p.user_bc_lower, p.user_bc_upper, t)
+    if p.ndim == 1:
+        dq, cfl = backend.sharp_flux1(p.rp, p.rp_params, p.lim_type, p.mwaves, p.mcapa + 1, mbc, q.shape[1],
+                                      p.qbc, p.auxbc, p.d[0], p.dt)
+    else:
+        mx, my = q.shape[1:]
+        dq, cfl = backend.sharp_flux2(p.rp, p.rp_params, p.lim_type, p.mwaves, p.mcapa + 1, mbc, mx, my,
+                                      p.qbc, p.auxbc, p.d[0], p.d[1], p.dt)
+    p.cfl = cfl                                            # CFL.update_global_max overwrites
+    if cfl > p.cfl_max:
+        raise CFLError()
+    return dq[inner]
+
+
+def sharp_step(p, backend):
+    """sharpclaw.py:152-210; q is rebound (not updated in place) exactly like the reference."""
+    try:
+        q, t, dt = p.q, p.t, p.dt
+        if p.time_integrator == 'Euler':
+            p.q = q + sharp_dq(p, backend, q, t)
+        elif p.time_integrator == 'SSP33':
+            s = q + sharp_dq(p, backend, q, t)
+            s = 0.75 * q + 0.25 * (s + sharp_dq(p, backend, s, t + dt))
+            p.q = 1. / 3. * q + 2. / 3. * (s + sharp_dq(p, backend, s, t + 0.5 * dt))
+        elif p.time_integrator == 'SSP104':
+            s1 = q + sharp_dq(p, backend, q, t) / 6.
+            s1t = t + dt / 6.
+            for i in range(4):
+                s1 = s1 + sharp_dq(p, backend, s1, s1t) / 6.
+                s1t = s1t + dt / 6.
+            s2 = q / 25. + 9. / 25 * s1
+            s1 = 15. * s2 - 5. * s1
+            s1t = t + dt / 3.
+            for i in range(4):
+                s1 = s1 + sharp_dq(p, backend, s1, s1t) / 6.
+                s1t = s1t + dt / 6.
+            p.q = s2 + 0.6 * s1 + 0.1 * sharp_dq(p, backend, s1, s1t)
+        else:
+            raise Exception('Unrecognized time integrator')
+    except CFLError:
+        return False
 
 
 def run(p, backend, tfinal, nout=1):
@@ -313,7 +377,7 @@ def shockbubble_problem(mx=160, my=40, with_src=True, dim_split=True, order_tran
         dim_split=dim_split, order_trans=order_trans)
 
 
-def acoustics2d_problem(mx=100, my=100, dim_split=True, order_trans=2, bcs=None):
+def acoustics2d_problem(mx=100, my=100, dim_split=True, order_trans=2, bcs=None, **kw):
     """test/acoustics/2d/homogeneous/acoustics.py:6-65 (classic variant)."""
     from oracle.oracle import RP_ACOUSTICS_2D
     x = centers(-1.0, 1.0, mx)
@@ -333,10 +397,10 @@ def acoustics2d_problem(mx=100, my=100, dim_split=True, order_trans=2, bcs=None)
     return Problem(
         q=q, d=d, rp=RP_ACOUSTICS_2D, rp_params=[rho, bulk, cc, zz], mwaves=2, limiters=[4] * 2,
         cfl_max=0.5, cfl_desired=0.45, dt_initial=np.min(d) / cc * 0.45,
-        bc_lower=bl, bc_upper=bu, dim_split=dim_split, order_trans=order_trans)
+        bc_lower=bl, bc_upper=bu, dim_split=dim_split, order_trans=order_trans, **kw)
 
 
-def acoustics1d_problem(mx=100):
+def acoustics1d_problem(mx=100, **kw):
     """test/acoustics/1d/homogeneous/acoustics.py:24-55 (classic Fortran variant; periodic, MC)."""
     from oracle.oracle import RP_ACOUSTICS_1D
     x = centers(0.0, 1.0, mx)
@@ -350,8 +414,8 @@ def acoustics1d_problem(mx=100):
     d = (1.0 / float(mx),)
     return Problem(
         q=q, d=d, rp=RP_ACOUSTICS_1D, rp_params=[rho, bulk, cc, zz], mwaves=2, limiters=[4] * 2,
-        cfl_max=1.0, cfl_desired=0.9, dt_initial=d[0] / cc * 0.1,
-        bc_lower=[PERIODIC], bc_upper=[PERIODIC])
+        cfl_max=kw.pop('cfl_max', 1.0), cfl_desired=kw.pop('cfl_desired', 0.9), dt_initial=d[0] / cc * 0.1,
+        bc_lower=[PERIODIC], bc_upper=[PERIODIC], **kw)
 
 
 def advection1d_problem(mx=1000, u=1.0, beta=100.0, x0=0.75):

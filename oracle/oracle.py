@@ -70,6 +70,14 @@ class COracle:
         L.orc_limiter.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip]
         L.orc_philim.restype = C.c_double
         L.orc_philim.argtypes = [C.c_double, C.c_double, C.c_int]
+        L.orc_sharp_flux2.restype = C.c_int
+        L.orc_sharp_flux2.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp]
+        L.orc_sharp_flux1.restype = C.c_int
+        L.orc_sharp_flux1.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp]
+        L.orc_weno5.restype = None
+        L.orc_weno5.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
 
     # -- f2py-shaped entry points -------------------------------------------------
     def step2ds(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim, ids,
@@ -121,6 +129,41 @@ class COracle:
         if rc:
             raise RuntimeError("oracle: unknown Riemann solver id %d" % rp)
         return q, cfl.value
+
+    # -- SharpClaw (sharpclaw_oracle.c) ------------------------------------------------
+    def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt):
+        """sharpclaw2.flux2(q,aux,dt,t,mbc,maxm,mx,my) -> (dq,cfl)  (sharpclaw.py:558)"""
+        meqn = q.shape[0]
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        maux = 0 if aux is None else aux.shape[0]
+        dq = np.zeros(q.shape, order="F")
+        cfl = C.c_double(0.0)
+        assert q.flags.f_contiguous
+        rc = self.lib.orc_sharp_flux2(rp, _d(par), lim_type, meqn, mwaves, maux, mcapa, mbc, mx, my, _d(q),
+                                      _d(dq), _d(aux) if maux else None, dx, dy, dt, C.byref(cfl))
+        if rc:
+            raise RuntimeError("oracle sharpclaw: rc=%d" % rc)
+        return dq, cfl.value
+
+    def sharp_flux1(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, q, aux, dx, dt):
+        """sharpclaw1.flux1(q,aux,dt,t,ixy,mx,mbc,maxnx) -> (dq,cfl)  (sharpclaw.py:385)"""
+        meqn = q.shape[0]
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        maux = 0 if aux is None else aux.shape[0]
+        dq = np.zeros(q.shape, order="F")
+        cfl = C.c_double(0.0)
+        rc = self.lib.orc_sharp_flux1(rp, _d(par), lim_type, meqn, mwaves, maux, mcapa, mbc, mx, _d(_f64(q)),
+                                      _d(dq), _d(aux) if maux else None, dx, dt, C.byref(cfl))
+        if rc:
+            raise RuntimeError("oracle sharpclaw: rc=%d" % rc)
+        return dq, cfl.value
+
+    def weno5(self, variant, mbc, q):
+        meqn, n = q.shape
+        ql = np.zeros((meqn, n), order="F")
+        qr = np.zeros((meqn, n), order="F")
+        self.lib.orc_weno5(variant, meqn, n, mbc, _d(_f64(q)), _d(ql), _d(qr))
+        return ql, qr
 
     # -- slice-level pieces -------------------------------------------------------
     def rpn2(self, rp, par, ixy, mwaves, mbc, mx, q1d):
@@ -224,3 +267,42 @@ class RefEuler2D:
         assert rp == RP_EULER5_2D and not fwave
         return self._call("step2_", par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method,
                           mthlim, None)
+
+
+class RefSharp2DEuler:
+    """The reference's SharpClaw Fortran (2d/sharpclaw/flux2.f90, flux1.f90, 1d/sharpclaw/weno.f90,
+    reconstruct.f90 + vendored Euler rpn2), flang-built, driven through oracle/ref_sharpclaw_shim.f90.
+    flux2_ takes 14 by-reference arguments in the order of flux2.f90:2."""
+
+    class _CParam(C.Structure):
+        _fields_ = [("gamma", C.c_double), ("gamma1", C.c_double)]
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "_ref", "libref_sharpclaw2d_euler.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.cparam = self._CParam.in_dll(self.lib, "cparam_")
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "libref_sharpclaw2d_euler.so"))
+
+    def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt):
+        assert rp == RP_EULER5_2D and mcapa == 0
+        self.cparam.gamma, self.cparam.gamma1 = float(par[0]), float(par[1])
+        meqn = q.shape[0]
+        maxnx = max(mx, my) + 2 * mbc                      # sharpclaw.py:280
+        dxs = np.array([dx, dy])
+        mth = np.array([1] * mwaves, dtype=np.int32)
+        self.lib.sc_setup(C.c_int(2), C.c_int(meqn), C.c_int(mwaves), C.c_int(mbc), C.c_int(maxnx),
+                          C.c_int(lim_type), C.c_int(5), C.c_int(0), C.c_int(0), _d(dxs), _i(mth))
+        dq = np.zeros(q.shape, order="F")
+        q1d = np.zeros((meqn, maxnx + 2 * mbc), order="F")
+        dq1d = np.zeros((meqn, maxnx + 2 * mbc), order="F")
+        auxd = np.zeros((1,) + q.shape[1:], order="F")
+        cfl = C.c_double()
+        ci = lambda v: C.byref(C.c_int(v))
+        self.lib.flux2_(_d(q), _d(dq), _d(q1d), _d(dq1d), _d(auxd), C.byref(C.c_double(dt)), C.byref(cfl),
+                        C.byref(C.c_double(0.0)), ci(0), ci(meqn), ci(mbc), ci(max(mx, my)), ci(mx), ci(my))
+        return dq, cfl.value

@@ -1,0 +1,223 @@
+/*
+ * oracle/sharpclaw_oracle.c -- TEST INFRASTRUCTURE ONLY (parity oracle, see classic_oracle.c).
+ *
+ * C restatement of the reference's SharpClaw semi-discrete right-hand side:
+ *   flux2 (2-D slice driver)  src/fortran/2d/sharpclaw/flux2.f90:32-94
+ *   flux1                     src/fortran/2d/sharpclaw/flux1.f90:59-188 (1-D twin 1d/sharpclaw/flux1.f90)
+ *   weno5 (PyWENO-generated)  src/fortran/1d/sharpclaw/weno.f90:36-100   lim_type=2, char_decomp=0
+ *   weno5 (legacy)            src/fortran/1d/sharpclaw/reconstruct.f90:120-185   lim_type=3
+ * Only char_decomp=0, tfluct_solver=.false. (the configurations the reference's tests use).
+ *
+ * The PyWENO source writes its constants WITHOUT a d0 exponent (+3.33333333333333, +0.1, 1.0e-36):
+ * they are REAL*4 literals promoted to double; the legacy routine's epweno = 1.e-36 likewise.
+ * F32() below reproduces that (float32-rounded constants => diff 0.0 vs flang).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+int orc_rpn2_ptr(int rp, const double *par, int ixy, int meqn, int mwaves, int mbc, int mx,
+                 const double *ql, const double *qr, double *wave, double *s, double *amdq, double *apdq);
+int orc_rp1_ptr(int rp, const double *par, int meqn, int mwaves, int mbc, int mx, const double *ql,
+                const double *qr, double *wave, double *s, double *amdq, double *apdq);
+
+#define F32(x) ((double)(float)(x))
+
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+
+/* q, ql, qr: (meqn, n) Fortran order, 1-based second index i = 1..n in the Fortran; here 0-based k=i-1 */
+#define Q(m, i) q[(m) + meqn * ((i)-1)]
+#define QL(m, i) ql[(m) + meqn * ((i)-1)]
+#define QR(m, i) qr[(m) + meqn * ((i)-1)]
+
+/* weno.f90:36-100; loop i = mbc-1 .. maxnx+mbc+1 restricted to indices whose stencil is in range */
+static void weno5_pyweno(const double *q, double *ql, double *qr, int meqn, int n, int ilo, int ihi)
+{
+    const double c333 = F32(+3.33333333333333), c1033 = F32(-10.3333333333333), c366 = F32(+3.66666666666667);
+    const double c833 = F32(+8.33333333333333), c633 = F32(-6.33333333333333), c133 = F32(+1.33333333333333);
+    const double c433m = F32(-4.33333333333333), c166 = F32(+1.66666666666667), c433 = F32(+4.33333333333333);
+    const double eps = F32(1.0e-36), w01 = F32(+0.1), w06 = F32(+0.6), w03 = F32(+0.3);
+    const double f183 = F32(+1.83333333333333), f116 = F32(-1.16666666666667), f033 = F32(+0.333333333333333);
+    const double f083 = F32(+0.833333333333333), f016 = F32(-0.166666666666667);
+    (void)n;
+    for (int i = ilo; i <= ihi; i++)
+        for (int m = 0; m < meqn; m++) {
+            double qm2 = Q(m, i - 2), qm1 = Q(m, i - 1), q0 = Q(m, i), qp1 = Q(m, i + 1), qp2 = Q(m, i + 2);
+            double sigma0 = ((c333 * q0) * q0) + ((c1033 * q0) * qp1) + ((c366 * q0) * qp2) +
+                            ((c833 * qp1) * qp1) + ((c633 * qp1) * qp2) + ((c133 * qp2) * qp2);
+            double sigma1 = ((c133 * qm1) * qm1) + ((c433m * qm1) * q0) + ((c166 * qm1) * qp1) +
+                            ((c433 * q0) * q0) + ((c433m * q0) * qp1) + ((c133 * qp1) * qp1);
+            double sigma2 = ((c133 * qm2) * qm2) + ((c633 * qm2) * qm1) + ((c366 * qm2) * q0) +
+                            ((c833 * qm1) * qm1) + ((c1033 * qm1) * q0) + ((c333 * q0) * q0);
+            double acc = 0.0, t;
+            t = sigma0 + eps; double omega0 = w01 / (t * t); acc = acc + omega0;
+            t = sigma1 + eps; double omega1 = w06 / (t * t); acc = acc + omega1;
+            t = sigma2 + eps; double omega2 = w03 / (t * t); acc = acc + omega2;
+            omega0 = omega0 / acc; omega1 = omega1 / acc; omega2 = omega2 / acc;
+            acc = 0.0;
+            t = sigma0 + eps; double omega3 = w03 / (t * t); acc = acc + omega3;
+            t = sigma1 + eps; double omega4 = w06 / (t * t); acc = acc + omega4;
+            t = sigma2 + eps; double omega5 = w01 / (t * t); acc = acc + omega5;
+            omega3 = omega3 / acc; omega4 = omega4 / acc; omega5 = omega5 / acc;
+            double fr0 = f183 * q0 + f116 * qp1 + f033 * qp2;
+            double fr1 = f033 * qm1 + f083 * q0 + f016 * qp1;
+            double fr2 = f016 * qm2 + f083 * qm1 + f033 * q0;
+            double fr3 = f033 * q0 + f083 * qp1 + f016 * qp2;
+            double fr4 = f016 * qm1 + f083 * q0 + f033 * qp1;
+            double fr5 = f033 * qm2 + f116 * qm1 + f183 * q0;
+            QL(m, i) = omega0 * fr0 + omega1 * fr1 + omega2 * fr2;
+            QR(m, i) = omega3 * fr3 + omega4 * fr4 + omega5 * fr5;
+        }
+}
+
+/* reconstruct.f90:120-185.  uu(1,i) -> qr(i-1), uu(2,i) -> ql(i); i = mbc .. mx2-mbc+1 */
+static void weno5_legacy(const double *q, double *ql, double *qr, int meqn, int mx2, int mbc)
+{
+    const double epweno = F32(1.e-36);
+    double *dq1m = calloc((size_t)mx2 + 4, sizeof(double));
+#define DQ(i) dq1m[(i)]
+    for (int m = 0; m < meqn; m++) {
+        for (int i = 2; i <= mx2; i++) DQ(i) = Q(m, i) - Q(m, i - 1);
+        for (int m1 = 1; m1 <= 2; m1++) {
+            int im = (m1 == 1) ? 1 : -1;
+            int ione = im, inone = -im, intwo = -2 * im;
+            for (int i = mbc; i <= mx2 - mbc + 1; i++) {
+                double t1 = im * (DQ(i + intwo) - DQ(i + inone));
+                double t2 = im * (DQ(i + inone) - DQ(i));
+                double t3 = im * (DQ(i) - DQ(i + ione));
+                double a1 = DQ(i + intwo) - 3. * DQ(i + inone);
+                double a2 = DQ(i + inone) + DQ(i);
+                double a3 = 3. * DQ(i) - DQ(i + ione);
+                double tt1 = 13. * (t1 * t1) + 3. * (a1 * a1);
+                double tt2 = 13. * (t2 * t2) + 3. * (a2 * a2);
+                double tt3 = 13. * (t3 * t3) + 3. * (a3 * a3);
+                tt1 = (epweno + tt1) * (epweno + tt1);
+                tt2 = (epweno + tt2) * (epweno + tt2);
+                tt3 = (epweno + tt3) * (epweno + tt3);
+                double s1 = tt2 * tt3;
+                double s2 = 6. * tt1 * tt3;
+                double s3 = 3. * tt1 * tt2;
+                double t0 = 1. / (s1 + s2 + s3);
+                s1 = s1 * t0;
+                s3 = s3 * t0;
+                double uu = (s1 * (t2 - t1) + (0.5 * s3 - 0.25) * (t3 - t2)) / 3. +
+                            (-Q(m, i - 2) + 7. * (Q(m, i - 1) + Q(m, i)) - Q(m, i + 1)) / 12.;
+                if (m1 == 1) QR(m, i - 1) = uu;
+                else QL(m, i) = uu;
+            }
+        }
+    }
+#undef DQ
+    free(dq1m);
+}
+
+/* flux1.f90:59-188 on one slice.  q1d (meqn, 1-mbc:mx+mbc); dq1d same extent, returned. */
+static int flux1(int ndim, int rp, const double *par, int lim_type, int ixy, int meqn, int mwaves, int mbc,
+                 int mx, const double *q1d, double *dq1d, const double *dtdx, double *cfl_out, double *work)
+{
+    const int n = mx + 2 * mbc;
+    double *ql = work, *qr = ql + (size_t)meqn * n, *wave = qr + (size_t)meqn * n;
+    double *s = wave + (size_t)meqn * mwaves * n, *amdq = s + (size_t)mwaves * n;
+    double *apdq = amdq + (size_t)meqn * n, *amdq2 = apdq + (size_t)meqn * n, *apdq2 = amdq2 + (size_t)meqn * n;
+    memset(work, 0, sizeof(double) * ((size_t)meqn * n * 6 + (size_t)meqn * mwaves * n + (size_t)mwaves * n));
+    const double *q = q1d;
+    /* the Fortran indexes the slice 1..maxnx+2mbc inside weno: i_weno = i_cell + mbc */
+    if (lim_type == 2)
+        weno5_pyweno(q, ql, qr, meqn, n, 3, n - 2);     /* every index whose 5-point stencil is in range */
+    else if (lim_type == 3)
+        weno5_legacy(q, ql, qr, meqn, n, mbc);
+    else
+        return -2;
+    int rc;
+    if (ndim == 1) rc = orc_rp1_ptr(rp, par, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
+    else rc = orc_rpn2_ptr(rp, par, ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
+    if (rc) return rc;
+#define IX(i) ((i) + mbc - 1)
+    double cfl = 0.0;
+    for (int mw = 0; mw < mwaves; mw++)
+        for (int i = 1; i <= mx + 1; i++) {
+            double sv = s[mw + mwaves * IX(i)];
+            cfl = dmax(dmax(cfl, dtdx[IX(i)] * sv), -dtdx[IX(i - 1)] * sv);
+        }
+    *cfl_out = cfl;
+    /* swap: in-cell Riemann problem between ql(i) and qr(i)  (flux1.f90:166-171) */
+    for (int i = 1 - mbc + 1; i <= mx + mbc; i++)
+        for (int m = 0; m < meqn; m++) {
+            qr[m + meqn * IX(i - 1)] = ql[m + meqn * IX(i)];
+            ql[m + meqn * IX(i)] = qr[m + meqn * IX(i)];
+        }
+    if (ndim == 1) rc = orc_rp1_ptr(rp, par, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq2, apdq2);
+    else rc = orc_rpn2_ptr(rp, par, ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq2, apdq2);
+    if (rc) return rc;
+    for (int i = 1; i <= mx; i++)
+        for (int m = 0; m < meqn; m++)
+            dq1d[m + meqn * IX(i)] = dq1d[m + meqn * IX(i)] -
+                                     dtdx[IX(i)] * (amdq[m + meqn * IX(i + 1)] + apdq[m + meqn * IX(i)] +
+                                                    amdq2[m + meqn * IX(i)] + apdq2[m + meqn * IX(i)]);
+#undef IX
+    return 0;
+}
+
+/* sharpclaw2.flux2(q,aux,dt,t,mbc,maxm,mx,my) -> (dq,cfl); dq (meqn, mx+2mbc, my+2mbc) zero-filled on entry */
+int orc_sharp_flux2(int rp, const double *par, int lim_type, int meqn, int mwaves, int maux, int mcapa,
+                    int mbc, int mx, int my, const double *q, double *dq, const double *aux, double dx,
+                    double dy, double dt, double *cfl_out)
+{
+    const int I = mx + 2 * mbc, J = my + 2 * mbc, nmax = (I > J ? I : J);
+    double *q1d = calloc((size_t)meqn * nmax, sizeof(double));
+    double *dq1d = calloc((size_t)meqn * nmax, sizeof(double));
+    double *dtdx = calloc(nmax, sizeof(double));
+    double *work = calloc((size_t)meqn * nmax * 6 + (size_t)meqn * mwaves * nmax + (size_t)mwaves * nmax, sizeof(double));
+    double cfl = 0.0, cfl1d;
+    int rc = 0;
+    memset(dq, 0, sizeof(double) * (size_t)meqn * I * J);
+#define G(m, i, j) ((m) + (size_t)meqn * (((i) + mbc - 1) + (size_t)I * ((j) + mbc - 1)))
+#define A(ma, i, j) aux[((ma)-1) + (size_t)maux * (((i) + mbc - 1) + (size_t)I * ((j) + mbc - 1))]
+    for (int j = 0; j <= my + 1 && !rc; j++) {
+        for (int i = 1 - mbc; i <= mx + mbc; i++) {
+            for (int m = 0; m < meqn; m++) q1d[m + meqn * (i + mbc - 1)] = q[G(m, i, j)];
+            dtdx[i + mbc - 1] = (mcapa > 0) ? dt / (dx * A(mcapa, i, j)) : dt / dx;
+        }
+        memset(dq1d, 0, sizeof(double) * (size_t)meqn * nmax);
+        rc = flux1(2, rp, par, lim_type, 1, meqn, mwaves, mbc, mx, q1d, dq1d, dtdx, &cfl1d, work);
+        cfl = dmax(cfl, cfl1d);
+        for (int i = 1; i <= mx; i++)
+            for (int m = 0; m < meqn; m++) dq[G(m, i, j)] = dq[G(m, i, j)] + dq1d[m + meqn * (i + mbc - 1)];
+    }
+    for (int i = 0; i <= mx + 1 && !rc; i++) {
+        for (int j = 1 - mbc; j <= my + mbc; j++) {
+            for (int m = 0; m < meqn; m++) q1d[m + meqn * (j + mbc - 1)] = q[G(m, i, j)];
+            dtdx[j + mbc - 1] = (mcapa > 0) ? dt / (dy * A(mcapa, i, j)) : dt / dy;
+        }
+        memset(dq1d, 0, sizeof(double) * (size_t)meqn * nmax);
+        rc = flux1(2, rp, par, lim_type, 2, meqn, mwaves, mbc, my, q1d, dq1d, dtdx, &cfl1d, work);
+        cfl = dmax(cfl, cfl1d);
+        for (int j = 1; j <= my; j++)
+            for (int m = 0; m < meqn; m++) dq[G(m, i, j)] = dq[G(m, i, j)] + dq1d[m + meqn * (j + mbc - 1)];
+    }
+    *cfl_out = cfl;
+    free(q1d); free(dq1d); free(dtdx); free(work);
+    return rc;
+}
+
+/* sharpclaw1.flux1(q,aux,dt,t,ixy,mx,mbc,maxnx) -> (dq,cfl) */
+int orc_sharp_flux1(int rp, const double *par, int lim_type, int meqn, int mwaves, int maux, int mcapa,
+                    int mbc, int mx, const double *q, double *dq, const double *aux, double dx, double dt,
+                    double *cfl_out)
+{
+    const int n = mx + 2 * mbc;
+    double *dtdx = calloc(n, sizeof(double));
+    double *work = calloc((size_t)meqn * n * 6 + (size_t)meqn * mwaves * n + (size_t)mwaves * n, sizeof(double));
+    for (int i = 0; i < n; i++)
+        dtdx[i] = (mcapa > 0) ? dt / (dx * aux[(mcapa - 1) + (size_t)maux * i]) : dt / dx;
+    memset(dq, 0, sizeof(double) * (size_t)meqn * n);   /* f2py zero-fills the optional dq1d */
+    int rc = flux1(1, rp, par, lim_type, 1, meqn, mwaves, mbc, mx, q, dq, dtdx, cfl_out, work);
+    free(dtdx); free(work);
+    return rc;
+}
+
+void orc_weno5(int variant, int meqn, int n, int mbc, const double *q, double *ql, double *qr)
+{
+    if (variant == 2) weno5_pyweno(q, ql, qr, meqn, n, 3, n - 2);
+    else weno5_legacy(q, ql, qr, meqn, n, mbc);
+}
