@@ -141,9 +141,15 @@ def ac2d_qinit(state, width=0.2):
     state.q[2, :, :] = 0.
 
 
-def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=True, math='exact'):
-    """test/acoustics/2d/homogeneous/acoustics.py:19-86 (classic)."""
-    solver = pyclaw.ClawSolver2D()
+def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=True, math='exact',
+                solver_type='classic', lim_type=2, time_integrator='SSP104'):
+    """test/acoustics/2d/homogeneous/acoustics.py:19-86 (classic or sharpclaw)."""
+    if solver_type == 'classic':
+        solver = pyclaw.ClawSolver2D()
+    else:
+        solver = pyclaw.SharpClawSolver2D()
+        solver.lim_type = lim_type
+        solver.time_integrator = time_integrator
     solver.math = math
     solver.rp = pyclaw.riemann.rp_acoustics_2d
     solver.cfl_max = 0.5
@@ -182,9 +188,14 @@ def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=T
     return claw
 
 
-def acoustics1D(pyclaw, mx=100):
-    """test/acoustics/1d/homogeneous/acoustics.py (classic): returns the one-period L1 error."""
-    solver = pyclaw.ClawSolver1D()
+def acoustics1D(pyclaw, mx=100, solver_type='classic', lim_type=2, time_integrator='SSP104'):
+    """test/acoustics/1d/homogeneous/acoustics.py: returns the one-period L1 error."""
+    if solver_type == 'classic':
+        solver = pyclaw.ClawSolver1D()
+    else:
+        solver = pyclaw.SharpClawSolver1D()
+        solver.lim_type = lim_type
+        solver.time_integrator = time_integrator
     solver.rp = pyclaw.riemann.rp_acoustics_1d
     x = pyclaw.Dimension('x', 0.0, 1.0, mx)
     grid = pyclaw.Grid(x)

@@ -65,6 +65,18 @@ extern "C" {
                          /* within ~1 ulp instead of correctly rounded).  Not bit-identical;*/
                          /* tested against the reference goldens at rtol 1e-12.            */
 
+/* solver kind: classic wave propagation (clawpack.py) or SharpClaw method of lines (sharpclaw.py) */
+#define PCL_KIND_CLASSIC 0
+#define PCL_KIND_SHARPCLAW 1
+
+/* SharpClaw registers: state q, the two Runge-Kutta stage registers (Solver._rk_stages,
+ * solver.py:266-291), the increment dq, and one scratch register (dq_src contributions) */
+#define PCL_REG_Q 0
+#define PCL_REG_S1 1
+#define PCL_REG_S2 2
+#define PCL_REG_DQ 3
+#define PCL_REG_TMP 4
+
 typedef struct pcl_solver pcl_solver;
 
 typedef struct pcl_config {
@@ -82,6 +94,8 @@ typedef struct pcl_config {
     double d[3];                    /* dx,dy,(dz)                                          */
     int device;                     /* HIP device ordinal                                  */
     int math;                       /* PCL_MATH_*                                          */
+    int kind;                       /* PCL_KIND_CLASSIC | PCL_KIND_SHARPCLAW               */
+    int lim_type;                   /* SharpClaw: 2 = WENO5 (PyWENO form), 3 = legacy WENO5 */
 } pcl_config;
 
 /* ---- library ---------------------------------------------------------------------- */
@@ -155,6 +169,18 @@ int pcl_restore(pcl_solver *s);
  *       aux[0] = radial coordinate; params = {gamma1, ndim}. */
 #define PCL_SRC_EULER_RADIAL 1
 int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int nparams);
+
+/* ---- SharpClaw (kind = PCL_KIND_SHARPCLAW) ----------------------------------------------------- */
+/* Which register the put/get/bc/strip/halo calls act on (default PCL_REG_Q): the RK stages get
+ * their ghost cells filled exactly like q (apply_q_bcs(stage), sharpclaw.py:546). */
+int pcl_select(pcl_solver *s, int reg);
+/* sharpclaw1.flux1 / sharpclaw2.flux2 (sharpclaw.py:385,558; flux1.f90, flux2.f90): dq register :=
+ * dt * dq/dt of the selected register (ghost cells must be filled); *cfl = local max Courant number. */
+int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl);
+/* Register arithmetic of the Runge-Kutta schemes (sharpclaw.py:168-206), evaluated in the order
+ * written: op 1: D = A + B/ca   2: D = ca*A + cb*(B + C)   3: D = A/ca + cb*B
+ *          4: D = ca*A - cb*B   5: D = A + cb*B + cc*C.  D, A, B, C are PCL_REG_* ids. */
+int pcl_rk_op(pcl_solver *s, int op, int D, int A, int B, int Cc, double ca, double cb, double cc);
 
 int pcl_sync(pcl_solver *s);
 

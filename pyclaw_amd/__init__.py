@@ -2,7 +2,7 @@
 pyclaw_amd -- MI355X-native implementation of PyClaw's data-parallel hot path.
 
 Same class names and solver surface as the reference package (``import pyclaw_amd as pyclaw``):
-Dimension, Grid, State, Solution, BC, ClawSolver1D/2D, Controller.  The classic
+Dimension, Grid, State, Solution, BC, ClawSolver1D/2D, SharpClawSolver1D/2D, Controller.  The classic
 wave-propagation step runs in hand-written HIP kernels (libpyclaw_amd.so, include/pyclaw_amd.h);
 there is no CPU fallback.
 """
@@ -11,9 +11,10 @@ from .cfl import CFL
 from .clawpack import ClawSolver1D, ClawSolver2D, DeviceSource, EulerRadialSource
 from .controller import Controller
 from .grid import Dimension, Grid
+from .sharpclaw import SharpClawSolver1D, SharpClawSolver2D
 from .solution import Solution
 from .solver import BC, ConstantStateBC, DeviceBC
 from .state import State
 
 __all__ = ['riemann', 'CFL', 'ClawSolver1D', 'ClawSolver2D', 'DeviceSource', 'EulerRadialSource',
-           'Controller', 'Dimension', 'Grid', 'Solution', 'BC', 'ConstantStateBC', 'DeviceBC', 'State']
+           'Controller', 'SharpClawSolver1D', 'SharpClawSolver2D', 'Dimension', 'Grid', 'Solution', 'BC', 'ConstantStateBC', 'DeviceBC', 'State']

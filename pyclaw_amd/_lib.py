@@ -38,6 +38,8 @@ class Config(C.Structure):
         ("d", C.c_double * 3),
         ("device", C.c_int),
         ("math", C.c_int),
+        ("kind", C.c_int),
+        ("lim_type", C.c_int),
     ]
 
 
@@ -68,6 +70,10 @@ PROTOTYPES = {
     "pcl_backup": (C.c_int, [C.c_void_p]),
     "pcl_restore": (C.c_int, [C.c_void_p]),
     "pcl_src": (C.c_int, [C.c_void_p, C.c_int, C.c_double, dp, C.c_int]),
+    "pcl_select": (C.c_int, [C.c_void_p, C.c_int]),
+    "pcl_sharp_dq": (C.c_int, [C.c_void_p, C.c_double, dp]),
+    "pcl_rk_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                            C.c_double]),
     "pcl_sync": (C.c_int, [C.c_void_p]),
     "pcl_timer_start": (C.c_int, [C.c_void_p]),
     "pcl_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

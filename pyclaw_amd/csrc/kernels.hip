@@ -10,6 +10,7 @@
 
 #include "../../include/pyclaw_amd.h"
 #include "classic.hpp"
+#include "sharpclaw.hpp"
 
 namespace pcl {
 namespace PCL_NS {
@@ -85,6 +86,52 @@ int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err) {
         hipLaunchKernelGGL(combine_kernel<false>, grid, dim3(256), 0, stream, c);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "combine launch", e);
+}
+
+// SharpClaw: dq of one direction (x writes dq, y accumulates)
+namespace {
+template <class RP, int IXY> int launch_sharp_t(const SweepLaunch &l, std::string &err) {
+    const SweepArgs &a = l.a;
+    const int n_across = IXY == 1 ? a.J : a.I + (LINE - a.mbc);
+    const int m_along = IXY == 1 ? a.mx : a.my;
+    const int ntiles_across = (n_across + T_ACROSS_S - 1) / T_ACROSS_S;
+    const int ntiles_along = (m_along + SSTRIP - 1) / SSTRIP;
+    const dim3 grid((unsigned)ntiles_across * (unsigned)ntiles_along);
+    const bool capa = a.mcapa > 0;
+#define PCL_SHARP_LAUNCH(CAPA_, LIM_)                                                                  \
+    hipLaunchKernelGGL((sharp_kernel<RP, IXY, CAPA_, LIM_>), grid, dim3(256), 0, l.stream, a, ntiles_across, \
+                       ntiles_along)
+    if (l.lim_type == 2) { if (capa) PCL_SHARP_LAUNCH(true, 2); else PCL_SHARP_LAUNCH(false, 2); }
+    else if (l.lim_type == 3) { if (capa) PCL_SHARP_LAUNCH(true, 3); else PCL_SHARP_LAUNCH(false, 3); }
+    else { err = "SharpClaw: lim_type must be 2 (WENO5) or 3 (legacy WENO5)"; return PCL_EINVAL; }
+#undef PCL_SHARP_LAUNCH
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "sharp launch", e);
+}
+}  // namespace
+
+int launch_sharp(const SweepLaunch &l, std::string &err) {
+    const int rp = l.rp;
+    if (l.ndim == 1) {
+        if (rp == PCL_RP_ADVECTION_1D) return launch_sharp_t<Advection1D, 1>(l, err);
+        if (rp == PCL_RP_ACOUSTICS_1D) return launch_sharp_t<Acoustics1D, 1>(l, err);
+    } else if (l.ids == 1) {
+        if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 1>(l, err);
+        if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 1>(l, err);
+    } else {
+        if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 2>(l, err);
+        if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 2>(l, err);
+    }
+    err = "Riemann solver id does not match the grid dimension";
+    return PCL_EINVAL;
+}
+
+int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err) {
+    RkOp o;
+    o.d = r.d; o.a = r.a; o.b = r.b; o.c = r.c; o.ca = r.ca; o.cb = r.cb; o.cc = r.cc; o.n = r.n; o.op = r.op;
+    hipLaunchKernelGGL(rk_kernel, dim3(2048), dim3(256), 0, stream, o);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "rk launch", e);
 }
 
 #if !PCL_FAST

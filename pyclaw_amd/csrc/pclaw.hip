@@ -39,6 +39,8 @@ struct pcl_solver {
                           // cell of every row starts a 128-byte line (16 - mbc)
     double *q = nullptr, *t1 = nullptr, *t2 = nullptr, *bak = nullptr;
     double *aux = nullptr;
+    double *sreg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // SharpClaw registers (0 aliases q)
+    int sel = 0;          // register the put/get/bc/strip/halo calls act on
     double *scr[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // unsplit slice pieces
     double *stage = nullptr;  // AoS staging for host transfers (qbc-sized)
     size_t stage_bytes = 0;
@@ -55,6 +57,8 @@ struct pcl_solver {
     long kt_n[2] = {0, 0};
     pcl::Halo halo;
 };
+
+static inline double *&cur(pcl_solver *s) { return s->sel == 0 ? s->q : s->sreg[s->sel]; }
 
 namespace pcl { namespace exact { void launch_shift_test(const double *in, double *l, double *r); } }
 
@@ -305,7 +309,13 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (!cfg || !out) return fail(PCL_EINVAL, "null argument");
     *out = nullptr;
     if (cfg->ndim < 1 || cfg->ndim > 2) return fail(PCL_EINVAL, "ndim must be 1 or 2");
-    if (cfg->mbc != 2) return fail(PCL_EINVAL, "classic kernels need mbc == 2 (reference default)");
+    if (cfg->kind == PCL_KIND_CLASSIC && cfg->mbc != 2)
+        return fail(PCL_EINVAL, "classic kernels need mbc == 2 (reference default)");
+    if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->mbc != 3)
+        return fail(PCL_EINVAL, "SharpClaw kernels implement weno_order 5: mbc == 3");
+    if (cfg->kind != PCL_KIND_CLASSIC && cfg->kind != PCL_KIND_SHARPCLAW) return fail(PCL_EINVAL, "unknown solver kind");
+    if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->lim_type != 2 && cfg->lim_type != 3)
+        return fail(PCL_EINVAL, "SharpClaw: lim_type must be 2 (WENO5) or 3 (legacy WENO5)");
     if (cfg->mwaves < 1 || cfg->mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
     if (cfg->math != PCL_MATH_EXACT && cfg->math != PCL_MATH_FAST) return fail(PCL_EINVAL, "unknown math mode");
     int want_meqn = 0, want_mwaves = 0, want_ndim = 0;
@@ -345,8 +355,12 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
         if (e == hipSuccess) *p = raw + s->lead;
     };
     alloc(&s->q, qbytes);
-    alloc(&s->t1, qbytes);
-    if (cfg->ndim > 1) alloc(&s->t2, qbytes);
+    if (cfg->kind == PCL_KIND_CLASSIC) {
+        alloc(&s->t1, qbytes);
+        if (cfg->ndim > 1) alloc(&s->t2, qbytes);
+    } else {
+        for (int k = 1; k < 5; k++) alloc(&s->sreg[k], qbytes);
+    }
     if (cfg->maux > 0) alloc(&s->aux, (size_t)s->plane * cfg->maux * sizeof(double));
     const int nmax = cfg->meqn > cfg->maux ? cfg->meqn : cfg->maux;
     s->stage_bytes = (size_t)nmax * s->I * s->J * sizeof(double);
@@ -376,6 +390,8 @@ void pcl_destroy(pcl_solver *s) {
         if (p) hipFree(p - s->lead);
     for (double *p : s->scr)
         if (p) hipFree(p - s->lead);
+    for (int k = 1; k < 5; k++)
+        if (s->sreg[k]) hipFree(s->sreg[k] - s->lead);
     hipFree(s->cfl_dev);
     if (s->cfl_host) hipHostFree(s->cfl_host);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -404,7 +420,7 @@ int pcl_put_q(pcl_solver *s, const double *host, int with_ghosts) {
     if (!s || !host) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     s->undo_slot = nullptr;
-    return put_array(s, host, s->q, s->cfg.meqn, with_ghosts);
+    return put_array(s, host, cur(s), s->cfg.meqn, with_ghosts);
 }
 
 int pcl_put_aux(pcl_solver *s, const double *host) {
@@ -424,7 +440,7 @@ int pcl_get_q(pcl_solver *s, double *host, int with_ghosts) {
     const int jo = (s->cfg.ndim > 1 && !with_ghosts) ? mbc : 0;
     const size_t bytes = (size_t)nm * ni * nj * sizeof(double);
     dim3 grid((ni + 255) / 256, nj);
-    hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, s->q, s->stage, nm, ni, nj, io, jo,
+    hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, cur(s), s->stage, nm, ni, nj, io, jo,
                        s->pitch, s->plane);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
@@ -450,7 +466,7 @@ int pcl_get_strip(pcl_solver *s, int idim, int side, int width, double *host) {
     if (int rc = strip_window(s, idim, side, width, ni, nj, io, jo)) return rc;
     const int nm = s->cfg.meqn;
     dim3 grid((ni + 255) / 256, nj);
-    hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, s->q, s->stage, nm, ni, nj, io, jo,
+    hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, cur(s), s->stage, nm, ni, nj, io, jo,
                        s->pitch, s->plane);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, s->stage, (size_t)nm * ni * nj * sizeof(double), hipMemcpyDeviceToHost,
@@ -468,7 +484,7 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
     HIP_TRY(hipMemcpyAsync(s->stage, host, (size_t)nm * ni * nj * sizeof(double), hipMemcpyHostToDevice,
                            s->stream));
     dim3 grid((ni + 255) / 256, nj);
-    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, s->q, nm, ni, nj, io, jo,
+    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, cur(s), nm, ni, nj, io, jo,
                        s->pitch, s->plane);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -478,7 +494,7 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
 static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate) {
     const int nt = idim == 0 ? s->J : s->I;
     const long n = (long)nt * s->cfg.mbc * s->cfg.meqn;
-    hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->q,
+    hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, cur(s),
                        s->cfg.meqn, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, idim, side, type, cstate);
     HIP_TRY(hipGetLastError());
     return PCL_OK;
@@ -506,6 +522,7 @@ int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state) {
 
 int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl) {
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     if (ids < 1 || ids > s->cfg.ndim) return fail(PCL_EINVAL, "bad ids");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
@@ -517,6 +534,7 @@ int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl) {
 
 int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
     if (s->cfg.ndim == 1) {
@@ -580,6 +598,52 @@ int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int npar
         return PCL_OK;
     }
     return fail(PCL_EINVAL, "unknown source id");
+}
+
+int pcl_select(pcl_solver *s, int reg) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (reg == 0) { s->sel = 0; return PCL_OK; }
+    if (s->cfg.kind != PCL_KIND_SHARPCLAW || reg < 0 || reg > 4) return fail(PCL_EINVAL, "bad register");
+    s->sel = reg;
+    return PCL_OK;
+}
+
+int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl) {
+    if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_ESTATE, "SharpClaw call on a classic solver");
+    if (s->sel == PCL_REG_DQ) return fail(PCL_EINVAL, "dq of the dq register");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
+    std::string err;
+    for (int ids = 1; ids <= s->cfg.ndim; ids++) {
+        SweepLaunch l;
+        l.a = make_args(s, cur(s), s->sreg[PCL_REG_DQ], ids, dt);
+        l.ndim = s->cfg.ndim; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave;
+        l.lim_type = s->cfg.lim_type; l.stream = s->stream;
+        pcl_solver::Timed t{};
+        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; hipEventRecord(t.a, s->stream); }
+        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sharp(l, err) : pcl::exact::launch_sharp(l, err);
+        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
+        if (rc) return fail(rc, err);
+    }
+    return read_cfl(s, cfl);
+}
+
+int pcl_rk_op(pcl_solver *s, int op, int D, int A, int B, int Cc, double ca, double cb, double cc) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_ESTATE, "SharpClaw call on a classic solver");
+    if (op < 1 || op > 5) return fail(PCL_EINVAL, "unknown RK op");
+    auto reg = [&](int r) -> double * { return r == 0 ? s->q : ((r > 0 && r < 5) ? s->sreg[r] : nullptr); };
+    RkLaunch r;
+    r.d = reg(D); r.a = reg(A); r.b = reg(B); r.c = reg(Cc);
+    if (!r.d || !r.a || !r.b || !r.c) return fail(PCL_EINVAL, "bad register");
+    r.ca = ca; r.cb = cb; r.cc = cc; r.op = op;
+    r.n = s->total;
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    std::string err;
+    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_rk(r, s->stream, err) : pcl::exact::launch_rk(r, s->stream, err);
+    if (rc) return fail(rc, err);
+    return PCL_OK;
 }
 
 int pcl_sync(pcl_solver *s) {
@@ -702,7 +766,7 @@ int pcl_halo_exchange(pcl_solver *s) {
     if (!s) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     std::string err;
-    if (s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);
+    if (s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);
     return PCL_OK;
 }
 

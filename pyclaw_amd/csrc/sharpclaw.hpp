@@ -1,0 +1,243 @@
+// sharpclaw.hpp -- SharpClaw semi-discrete right-hand side (dq = dt * dq/dt) as a gfx950 kernel.
+//
+// Reference path restated (operation order preserved):
+//   flux2 (slice driver)   src/fortran/2d/sharpclaw/flux2.f90:32-94
+//   flux1                  src/fortran/2d/sharpclaw/flux1.f90:59-188   (char_decomp=0, no tfluct)
+//   weno5, PyWENO form     src/fortran/1d/sharpclaw/weno.f90:36-100    (lim_type=2)
+//   weno5, legacy form     src/fortran/1d/sharpclaw/reconstruct.f90:120-185 (lim_type=3)
+//
+// Same mapping as the classic kernel (classic.hpp): one lane = one cell of a 64-cell strip, a
+// 64 x 16 tile staged through LDS, but a 3-cell halo (WENO5 needs q(i-2..i+2) and the update needs
+// the interface on either side): lanes 3..60 produce dq.  Per cell: one WENO reconstruction
+// (its stencil read straight from the LDS tile), the Riemann problem at interface i (left
+// neighbour's right-edge state arrives by wavefront shift) and the Riemann problem INSIDE the
+// cell between its own edge states (flux1.f90:166-187).
+#pragma once
+#include "classic.hpp"
+
+namespace pcl {
+namespace PCL_NS {
+
+constexpr int T_ACROSS_S = 16;
+constexpr int SHALO = 3;
+constexpr int SSTRIP = WAVE - 2 * SHALO;  // 58 cells updated per strip
+
+// REAL*4 literals of the generated Fortran, promoted to double (weno.f90 has no d0 exponents)
+#define PCL_F32(x) ((double)(float)(x))
+
+// weno.f90:36-100 for one component: q(i-2..i+2) -> ql(i), qr(i)
+__device__ __forceinline__ void weno5_pyweno(double qm2, double qm1, double q0, double qp1, double qp2,
+                                             double &ql, double &qr) {
+    constexpr double c333 = PCL_F32(+3.33333333333333), c1033 = PCL_F32(-10.3333333333333);
+    constexpr double c366 = PCL_F32(+3.66666666666667), c833 = PCL_F32(+8.33333333333333);
+    constexpr double c633 = PCL_F32(-6.33333333333333), c133 = PCL_F32(+1.33333333333333);
+    constexpr double c433m = PCL_F32(-4.33333333333333), c166 = PCL_F32(+1.66666666666667);
+    constexpr double c433 = PCL_F32(+4.33333333333333);
+    constexpr double eps = PCL_F32(1.0e-36), w01 = PCL_F32(+0.1), w06 = PCL_F32(+0.6), w03 = PCL_F32(+0.3);
+    constexpr double f183 = PCL_F32(+1.83333333333333), f116 = PCL_F32(-1.16666666666667);
+    constexpr double f033 = PCL_F32(+0.333333333333333), f083 = PCL_F32(+0.833333333333333);
+    constexpr double f016 = PCL_F32(-0.166666666666667);
+    const double sigma0 = ((c333 * q0) * q0) + ((c1033 * q0) * qp1) + ((c366 * q0) * qp2) +
+                          ((c833 * qp1) * qp1) + ((c633 * qp1) * qp2) + ((c133 * qp2) * qp2);
+    const double sigma1 = ((c133 * qm1) * qm1) + ((c433m * qm1) * q0) + ((c166 * qm1) * qp1) +
+                          ((c433 * q0) * q0) + ((c433m * q0) * qp1) + ((c133 * qp1) * qp1);
+    const double sigma2 = ((c133 * qm2) * qm2) + ((c633 * qm2) * qm1) + ((c366 * qm2) * q0) +
+                          ((c833 * qm1) * qm1) + ((c1033 * qm1) * q0) + ((c333 * q0) * q0);
+    const double t0 = sigma0 + eps, t1 = sigma1 + eps, t2 = sigma2 + eps;
+    const double d0 = t0 * t0, d1 = t1 * t1, d2 = t2 * t2;
+    double acc = 0.0;
+    double omega0 = fdiv_ieee(w01, d0); acc = acc + omega0;
+    double omega1 = fdiv_ieee(w06, d1); acc = acc + omega1;
+    double omega2 = fdiv_ieee(w03, d2); acc = acc + omega2;
+    omega0 = fdiv_ieee(omega0, acc); omega1 = fdiv_ieee(omega1, acc); omega2 = fdiv_ieee(omega2, acc);
+    acc = 0.0;
+    double omega3 = fdiv_ieee(w03, d0); acc = acc + omega3;
+    double omega4 = fdiv_ieee(w06, d1); acc = acc + omega4;
+    double omega5 = fdiv_ieee(w01, d2); acc = acc + omega5;
+    omega3 = fdiv_ieee(omega3, acc); omega4 = fdiv_ieee(omega4, acc); omega5 = fdiv_ieee(omega5, acc);
+    const double fr0 = f183 * q0 + f116 * qp1 + f033 * qp2;
+    const double fr1 = f033 * qm1 + f083 * q0 + f016 * qp1;
+    const double fr2 = f016 * qm2 + f083 * qm1 + f033 * q0;
+    const double fr3 = f033 * q0 + f083 * qp1 + f016 * qp2;
+    const double fr4 = f016 * qm1 + f083 * q0 + f033 * qp1;
+    const double fr5 = f033 * qm2 + f116 * qm1 + f183 * q0;
+    ql = omega0 * fr0 + omega1 * fr1 + omega2 * fr2;
+    qr = omega3 * fr3 + omega4 * fr4 + omega5 * fr5;
+}
+
+// reconstruct.f90:147-176: the interface value uu(m1,i) between cells i-1 and i.
+// d2,d1,d0,dp1 = dq1m(i+intwo), dq1m(i+inone), dq1m(i), dq1m(i+ione); im = +1 (from the left) / -1
+__device__ __forceinline__ double weno5_legacy_edge(double im, double d2, double d1, double d0, double dp1,
+                                                    double qim2, double qim1, double qi, double qip1) {
+    constexpr double epweno = PCL_F32(1.e-36);
+    const double t1 = im * (d2 - d1);
+    const double t2 = im * (d1 - d0);
+    const double t3 = im * (d0 - dp1);
+    const double a1 = d2 - 3. * d1, a2 = d1 + d0, a3 = 3. * d0 - dp1;
+    double tt1 = 13. * (t1 * t1) + 3. * (a1 * a1);
+    double tt2 = 13. * (t2 * t2) + 3. * (a2 * a2);
+    double tt3 = 13. * (t3 * t3) + 3. * (a3 * a3);
+    tt1 = (epweno + tt1) * (epweno + tt1);
+    tt2 = (epweno + tt2) * (epweno + tt2);
+    tt3 = (epweno + tt3) * (epweno + tt3);
+    double s1 = tt2 * tt3;
+    const double s2 = 6. * tt1 * tt3;
+    double s3 = 3. * tt1 * tt2;
+    const double t0 = fdiv_ieee(1., s1 + s2 + s3);
+    s1 = s1 * t0;
+    s3 = s3 * t0;
+    return (s1 * (t2 - t1) + (0.5 * s3 - 0.25) * (t3 - t2)) / 3. + (-qim2 + 7. * (qim1 + qi) - qip1) / 12.;
+}
+
+// legacy weno5 for one component of cell c: ql(c) = uu(2,c), qr(c) = uu(1,c+1)
+__device__ __forceinline__ void weno5_legacy(double qm2, double qm1, double q0, double qp1, double qp2,
+                                             double &ql, double &qr) {
+    const double dm1 = qm1 - qm2;  // dq1m(c-1)
+    const double d0 = q0 - qm1;    // dq1m(c)
+    const double dp1 = qp1 - q0;   // dq1m(c+1)
+    const double dp2 = qp2 - qp1;  // dq1m(c+2)
+    // uu(2,i=c): im=-1, ione=-1, inone=+1, intwo=+2; central part uses q(i-2..i+1) = q(c-2..c+1)
+    ql = weno5_legacy_edge(-1.0, dp2, dp1, d0, dm1, qm2, qm1, q0, qp1);
+    // uu(1,i=c+1): im=+1, intwo=-2 -> dq1m(c-1), inone=-1 -> dq1m(c), dq1m(c+1), ione -> dq1m(c+2);
+    // central part q(i-2..i+1) = q(c-1..c+2)
+    qr = weno5_legacy_edge(+1.0, dm1, d0, dp1, dp2, qm1, q0, qp1, qp2);
+}
+
+// ---- the kernel ----------------------------------------------------------------------------------
+// x pass (IXY=1): dq(interior) = dq1d ; y pass (IXY=2): dq += dq1d   (flux2.f90:54-56,86-88)
+template <int IXY> __device__ __forceinline__ int stile_at(int m, int al, int ac) {
+    return IXY == 1 ? (m * T_ACROSS_S + ac) * WAVE + al : (m * WAVE + al) * (T_ACROSS_S + 1) + ac;
+}
+
+template <class RP, int IXY, bool CAPA, int LIM>
+__global__ __launch_bounds__(256) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
+    constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
+    constexpr int NP = MEQN + (CAPA ? 1 : 0);
+    constexpr int PLANE = IXY == 1 ? T_ACROSS_S * WAVE : WAVE * (T_ACROSS_S + 1);
+    using Cell = typename RP::Cell;
+    __shared__ double tile[NP * PLANE];
+
+    const int n_along = IXY == 1 ? a.I : a.J;
+    const int n_across = IXY == 1 ? a.J : a.I;
+    const int m_along = IXY == 1 ? a.mx : a.my;
+    const int m_across = IXY == 1 ? a.my : a.mx;
+    const int tb = IXY == 1 ? blockIdx.x / ntiles_along : blockIdx.x % ntiles_across;
+    const int ta = IXY == 1 ? blockIdx.x % ntiles_along : blockIdx.x / ntiles_across;
+    const int b0 = IXY == 1 ? tb * T_ACROSS_S : tb * T_ACROSS_S - (LINE - a.mbc);
+    const int a0 = a.mbc - SHALO + ta * SSTRIP;
+
+    // cooperative load (memory-contiguous index fastest)
+    const int l_al = IXY == 1 ? threadIdx.x % WAVE : threadIdx.x / T_ACROSS_S;
+    const int l_ac = IXY == 1 ? threadIdx.x / WAVE : threadIdx.x % T_ACROSS_S;
+    constexpr int STEP_AL = IXY == 1 ? 0 : 256 / T_ACROSS_S;
+    constexpr int STEP_AC = IXY == 1 ? 256 / WAVE : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
+        int ga = a0 + al, gb = b0 + ac;
+        ga = ga < n_along ? ga : n_along - 1;
+        gb = gb < 0 ? 0 : (gb < n_across ? gb : n_across - 1);
+        const long g = IXY == 1 ? (long)gb * a.pitch + ga : (long)ga * a.pitch + gb;
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) tile[stile_at<IXY>(m, al, ac)] = a.qin[m * a.plane + g];
+        if constexpr (CAPA) tile[stile_at<IXY>(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x / WAVE;
+    const int ca = a0 + lane;
+    const bool owned = (ca >= a.mbc) && (ca < a.mbc + m_along) && lane >= SHALO && lane < WAVE - SHALO;
+    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + m_along) && lane >= SHALO && lane <= WAVE - SHALO;
+    const bool one_d = a.J == 1;  // 1-D grids have no transverse ghost layers
+    // stencil positions clamped inside the strip (end lanes never feed a stored value)
+    const int lm2 = lane >= 2 ? lane - 2 : 0, lm1 = lane >= 1 ? lane - 1 : 0;
+    const int lp1 = lane <= WAVE - 2 ? lane + 1 : WAVE - 1, lp2 = lane <= WAVE - 3 ? lane + 2 : WAVE - 1;
+    double cflmax = 0.0;
+    for (int ac = wv; ac < T_ACROSS_S; ac += 256 / WAVE) {
+        const int gb = b0 + ac;
+        if (gb >= n_across) break;  // wave-uniform
+        // flux2.f90:38,70: slices 0..m+1 only (one ghost layer)
+        if (!one_d && (gb < a.mbc - 1 || gb > a.mbc + m_across)) continue;
+        double ql[MEQN], qr[MEQN];
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {
+            const double qm2 = tile[stile_at<IXY>(m, lm2, ac)], qm1 = tile[stile_at<IXY>(m, lm1, ac)];
+            const double q0 = tile[stile_at<IXY>(m, lane, ac)];
+            const double qp1 = tile[stile_at<IXY>(m, lp1, ac)], qp2 = tile[stile_at<IXY>(m, lp2, ac)];
+            if (LIM == 2) weno5_pyweno(qm2, qm1, q0, qp1, qp2, ql[m], qr[m]);
+            else weno5_legacy(qm2, qm1, q0, qp1, qp2, ql[m], qr[m]);
+        }
+        double dtdx_c = a.dtd;
+        if constexpr (CAPA) dtdx_c = a.dt / (a.dx * tile[stile_at<IXY>(MEQN, lane, ac)]);  // flux1.f90:60
+        const double dtdx_l = CAPA ? from_left(dtdx_c) : dtdx_c;
+
+        const Cell cl = RP::template precell<IXY>(ql, a.par);   // left-edge state of this cell
+        const Cell cr = RP::template precell<IXY>(qr, a.par);   // right-edge state of this cell
+        const Cell crl = struct_from_left(cr);                  // right-edge state of cell i-1
+        double wave[MWAVES][MEQN], s[MWAVES], amdq[MEQN], apdq[MEQN], amdq2[MEQN], apdq2[MEQN];
+        RP::template solve<IXY>(crl, cl, a.par, wave, s, amdq, apdq);       // interface i   (flux1.f90:125)
+        if (cfl_ok) {
+#pragma unroll
+            for (int mw = 0; mw < MWAVES; mw++)
+                cflmax = dmax(dmax(cflmax, dtdx_c * s[mw]), -dtdx_l * s[mw]);
+        }
+        RP::template solve<IXY>(cl, cr, a.par, wave, s, amdq2, apdq2);      // inside cell i (flux1.f90:182)
+        double dq1[MEQN];
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {  // the shift must run with every lane active
+            const double amdq_r = from_right(amdq[m]);
+            dq1[m] = -(dtdx_c * (amdq_r + apdq[m] + amdq2[m] + apdq2[m]));
+        }
+        if (owned) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) tile[stile_at<IXY>(m, lane, ac)] = dq1[m];
+        }
+    }
+    __syncthreads();
+
+    // cooperative store of dq for the owned interior cells
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
+        const int ga = a0 + al, gb = b0 + ac;
+        const bool inner_al = (ga >= a.mbc) && (ga < a.mbc + m_along) && al >= SHALO && al < WAVE - SHALO;
+        const bool inner_ac = gb >= 0 && gb < n_across && (one_d || ((gb >= a.mbc) && (gb < a.mbc + m_across)));
+        if (inner_al && inner_ac) {
+            const long g = IXY == 1 ? (long)gb * a.pitch + ga : (long)ga * a.pitch + gb;
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                const long at = m * a.plane + g;
+                const double v = tile[stile_at<IXY>(m, al, ac)];
+                a.qout[at] = IXY == 1 ? v : a.qout[at] + v;  // dq = (0 + dq1d_x) + dq1d_y
+            }
+        }
+    }
+    cfl_publish(a.cfl, cflmax);
+}
+
+// ---- Runge-Kutta register arithmetic (sharpclaw.py:168-206), elementwise over whole arrays ----------
+struct RkOp {
+    double *d;
+    const double *a, *b, *c;
+    double ca, cb, cc;
+    long n;
+    int op;
+};
+__global__ __launch_bounds__(256) void rk_kernel(RkOp o) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < o.n; i += (long)gridDim.x * blockDim.x) {
+        double r;
+        switch (o.op) {
+        case 1: r = o.a[i] + o.b[i] / o.ca; break;                          // A + B/c
+        case 2: r = o.ca * o.a[i] + o.cb * (o.b[i] + o.c[i]); break;        // a*A + b*(B + C)
+        case 3: r = o.a[i] / o.ca + o.cb * o.b[i]; break;                   // A/c + b*B
+        case 4: r = o.ca * o.a[i] - o.cb * o.b[i]; break;                   // a*A - b*B
+        case 5: r = o.a[i] + o.cb * o.b[i] + o.cc * o.c[i]; break;          // A + b*B + c*C
+        default: r = o.a[i];
+        }
+        o.d[i] = r;
+    }
+}
+
+}  // namespace PCL_NS
+}  // namespace pcl

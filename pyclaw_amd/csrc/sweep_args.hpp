@@ -45,12 +45,21 @@ struct CombineArgs {
     int I, J, mbc, mx, my, mcapa, meqn;
 };
 
+struct RkLaunch {
+    double *d;
+    const double *a, *b, *c;
+    double ca, cb, cc;
+    long n;
+    int op;
+};
+
 struct SweepLaunch {
     SweepArgs a;
     int ndim;   // 1 or 2
     int rp;     // PCL_RP_*
     int ids;    // 1 = x pass (or the 1-D step), 2 = y pass
     int fwave;
+    int lim_type;  // SharpClaw reconstruction (2 PyWENO weno5, 3 legacy weno5)
     hipStream_t stream;
 };
 
@@ -59,11 +68,15 @@ namespace exact {
 int launch_sweep(const SweepLaunch &l, std::string &err);
 int launch_slices(const SweepLaunch &l, std::string &err);   // unsplit: per-slice pieces -> scratch
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
+int launch_sharp(const SweepLaunch &l, std::string &err);     // SharpClaw dq of one direction
+int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 }
 namespace fast {
 int launch_sweep(const SweepLaunch &l, std::string &err);
 int launch_slices(const SweepLaunch &l, std::string &err);
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
+int launch_sharp(const SweepLaunch &l, std::string &err);
+int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 }
 
 }  // namespace pcl

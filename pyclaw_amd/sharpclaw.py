@@ -1,0 +1,258 @@
+r"""
+SharpClaw (method-of-lines) solvers on MI355X (reference: src/pyclaw/sharpclaw.py).
+
+``SharpClawSolver1D`` / ``SharpClawSolver2D`` keep the reference's attributes, Runge-Kutta
+schemes (Euler, SSP33, SSP104: sharpclaw.py:152-210) and CFL handling (``CFLError`` inside
+``dq`` => ``step`` returns False and ``evolve_to_time`` retakes the step).  ``dq_hyperbolic``
+(sharpclaw.py:343-447, 515-563: ``sharpclaw1.flux1`` / ``sharpclaw2.flux2``) runs in the HIP
+kernel of csrc/sharpclaw.hpp; the stage registers and the register arithmetic of the RK
+schemes live on the device too (``pcl_rk_op`` evaluates each formula in the order the
+reference's numpy expressions do).
+
+Implemented reconstruction: ``lim_type=2`` with ``weno_order=5`` (the PyWENO-generated ``weno5``,
+float32-rounded literals included) and ``lim_type=3`` (the legacy ``weno5`` of reconstruct.f90,
+the one the reference's golden ``test/ac_sc_solution`` was produced with); ``char_decomp=0``,
+``tfluct_solver=False``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib, riemann
+from .solver import Solver, BC
+from .state import State
+
+Q, S1, S2, DQ, TMP = 0, 1, 2, 3, 4
+
+
+class CFLError(Exception):
+    """Error raised when cfl_max is exceeded.  Is this a reasonable mechanism for handling that?"""
+
+    def __init__(self, msg):
+        super(CFLError, self).__init__(msg)
+
+
+def start_step(solver, solution):
+    r"""Dummy routine called before each step (sharpclaw.py:26-31)."""
+    pass
+
+
+class _StageState(object):
+    """What a Python custom-BC callback sees of an RK stage: time, grid, aux (solver.py:283-291)."""
+
+    def __init__(self, state):
+        self.grid = state.grid
+        self.aux = state.aux
+        self.aux_global = state.aux_global
+        self.decomp = state.decomp
+        self.t = state.t
+        self.q = None
+        self.mcapa = state.mcapa
+
+
+class SharpClawSolver(Solver):
+    r"""Superclass for all SharpClawND solvers (sharpclaw.py:34-283)."""
+
+    def __init__(self, data=None):
+        for attr in ['limiters', 'start_step', 'lim_type', 'weno_order', 'time_integrator', 'char_decomp',
+                     'aux_time_dep', 'mwaves']:
+            if attr not in self._required_attrs:
+                self._required_attrs.append(attr)
+        self._default_attr_values['limiters'] = [1]
+        self._default_attr_values['start_step'] = start_step
+        self._default_attr_values['lim_type'] = 2
+        self._default_attr_values['weno_order'] = 5
+        self._default_attr_values['time_integrator'] = 'SSP104'
+        self._default_attr_values['char_decomp'] = 0
+        self._default_attr_values['tfluct_solver'] = False
+        self._default_attr_values['aux_time_dep'] = False
+        self._default_attr_values['kernel_language'] = 'HIP'
+        self._default_attr_values['mbc'] = 3
+        self._default_attr_values['fwave'] = False
+        self._default_attr_values['cfl_desired'] = 2.45
+        self._default_attr_values['cfl_max'] = 2.5
+        self._default_attr_values['dq_src'] = None
+        self._default_attr_values['math'] = 'exact'
+        self.rp = None
+        super(SharpClawSolver, self).__init__(data)
+
+    # ------------------------------------------------------------------ RK step
+    def _op(self, op, D, A, B, Cc, ca=0.0, cb=0.0, cc=0.0):
+        _lib.check(_lib.lib().pcl_rk_op(self._h, op, D, A, B, Cc, ca, cb, cc))
+
+    def step(self, solution):
+        """Evolve q over one time step (sharpclaw.py:152-210).  Registers: q, s1, s2, dq on device."""
+        state = solution.states[0]
+        if self.start_step is not start_step:
+            self._pull(state)
+            self.start_step(self, solution)
+            self._push(state)
+        else:
+            self.start_step(self, solution)
+        t, dt = state.t, self.dt
+        try:
+            if self.time_integrator == 'Euler':
+                self.dq(Q, t)
+                self._op(1, Q, Q, DQ, Q, ca=1.0)                      # state.q += deltaq
+            elif self.time_integrator == 'SSP33':
+                self.dq(Q, t)
+                self._op(1, S1, Q, DQ, Q, ca=1.0)                     # s.q = state.q + deltaq
+                self.dq(S1, t + dt)
+                self._op(2, S1, Q, S1, DQ, ca=0.75, cb=0.25)          # 0.75*q + 0.25*(s.q+deltaq)
+                self.dq(S1, t + 0.5 * dt)
+                self._op(2, Q, Q, S1, DQ, ca=1. / 3., cb=2. / 3.)     # 1/3*q + 2/3*(s.q+deltaq)
+            elif self.time_integrator == 'SSP104':
+                self.dq(Q, t)
+                self._op(1, S1, Q, DQ, Q, ca=6.)                      # s1 = q + deltaq/6
+                s1t = t + dt / 6.
+                for i in range(4):
+                    self.dq(S1, s1t)
+                    self._op(1, S1, S1, DQ, Q, ca=6.)
+                    s1t = s1t + dt / 6.
+                self._op(3, S2, Q, S1, Q, ca=25., cb=9. / 25)         # s2 = q/25 + 9/25*s1
+                self._op(4, S1, S2, S1, Q, ca=15., cb=5.)             # s1 = 15*s2 - 5*s1
+                s1t = t + dt / 3.
+                for i in range(4):
+                    self.dq(S1, s1t)
+                    self._op(1, S1, S1, DQ, Q, ca=6.)
+                    s1t = s1t + dt / 6.
+                self.dq(S1, s1t)
+                self._op(5, Q, S2, S1, DQ, cb=0.6, cc=0.1)            # q = s2 + 0.6*s1 + 0.1*deltaq
+            else:
+                raise Exception('Unrecognized time integrator')
+            self._host_stale = True
+        except CFLError:
+            return False
+
+    def set_mthlim(self):
+        self.mthlim = self.limiters
+        if not isinstance(self.limiters, list):
+            self.mthlim = [self.mthlim]
+        if len(self.mthlim) == 1:
+            self.mthlim = self.mthlim * self.mwaves
+        if len(self.mthlim) != self.mwaves:
+            raise Exception('Length of solver.limiters is not equal to 1 or to solver.mwaves')
+
+    def dq(self, reg, t):
+        """Evaluate dq/dt * (delta t) of a register into the dq register (sharpclaw.py:221-237)."""
+        self.dq_hyperbolic(reg, t)
+        if self.cfl.get_cached_max() > self.cfl_max:
+            raise CFLError('cfl_max exceeded')
+        if self.dq_src is not None:
+            # arbitrary Python: round trip of the stage through the host
+            L = _lib.lib()
+            st = self._stage
+            st.t = t
+            st.q = np.empty(self._state.q.shape, order='F')
+            _lib.check(L.pcl_select(self._h, reg))
+            _lib.check(L.pcl_get_q(self._h, _lib.d(st.q), 0))
+            extra = _lib.fortran64(self.dq_src(self, st, self.dt))
+            _lib.check(L.pcl_select(self._h, TMP))
+            _lib.check(L.pcl_put_q(self._h, _lib.d(extra), 0))
+            _lib.check(L.pcl_select(self._h, Q))
+            self._op(1, DQ, DQ, TMP, Q, ca=1.0)                       # deltaq += dq_src(...)
+
+    def dq_hyperbolic(self, reg, t):
+        """apply_q_bcs(stage) + flux1/flux2 on the device (sharpclaw.py:343-385, 515-563)."""
+        L = _lib.lib()
+        st = self._stage
+        st.t = t
+        _lib.check(L.pcl_select(self._h, reg))
+        try:
+            self.apply_q_bcs(st)
+            cfl = ctypes.c_double(0.0)
+            _lib.check(L.pcl_sharp_dq(self._h, self.dt, ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+        finally:
+            _lib.check(L.pcl_select(self._h, Q))
+        self.cfl.update_global_max(cfl.value)
+
+    # a rejected SharpClaw step never wrote q (CFLError is raised before the final combination),
+    # so no backup is needed unless a user start_step changed q
+    def _backup(self, state):
+        self._copied_backup = self.start_step is not start_step
+        if self._copied_backup:
+            _lib.check(_lib.lib().pcl_backup(self._h))
+
+    def _restore(self, state):
+        if self._copied_backup:
+            _lib.check(_lib.lib().pcl_restore(self._h))
+            self._host_stale = True
+
+    # ------------------------------------------------------------------ setup
+    def setup(self, solution):
+        """Allocate RK registers and the device solver (sharpclaw.py:302-323, 474-495)."""
+        if self.kernel_language not in ('HIP', 'Fortran'):
+            raise Exception("Unrecognized value of solver.kernel_language.")
+        if self.weno_order != 5:
+            raise NotImplementedError("pyclaw_amd SharpClaw implements weno_order=5")
+        if self.lim_type not in (2, 3):
+            raise NotImplementedError("pyclaw_amd SharpClaw implements lim_type 2 (WENO5) and 3 (legacy WENO5)")
+        if self.char_decomp != 0 or self.tfluct_solver:
+            raise NotImplementedError("pyclaw_amd SharpClaw implements char_decomp=0, tfluct_solver=False")
+        if self.time_integrator not in ('Euler', 'SSP33', 'SSP104'):
+            raise Exception('Unrecognized time integrator')
+        self.mbc = (self.weno_order + 1) // 2
+        state = solution.states[0]
+        state.set_mbc(self.mbc)
+        self.set_mthlim()
+        if self.rp is None:
+            raise Exception("solver.rp is not set: choose a Riemann solver from pyclaw_amd.riemann")
+        rp = riemann.get(self.rp)
+        if rp.ndim != self.ndim or rp.mwaves != self.mwaves or rp.meqn != state.meqn:
+            raise Exception("Riemann solver %s does not match ndim/mwaves/meqn of the problem" % rp.name)
+        params = rp.params(state.aux_global)
+
+        self._release()
+        cfg = _lib.Config()
+        cfg.ndim = self.ndim
+        for k in range(self.ndim):
+            cfg.n[k] = int(state.grid.ng[k])
+            cfg.d[k] = float(state.grid.d[k])
+        cfg.mbc = self.mbc
+        cfg.meqn = state.meqn
+        cfg.mwaves = self.mwaves
+        cfg.maux = state.maux
+        cfg.method[1] = 2
+        cfg.method[5] = state.mcapa + 1
+        cfg.method[6] = state.maux
+        cfg.fwave = int(bool(self.fwave))
+        cfg.rp = rp.id
+        for k, v in enumerate(params):
+            cfg.rp_params[k] = v
+        from . import parallel
+        cfg.device = parallel.local_rank() if state.decomp is not None else int(getattr(self, 'device', 0))
+        if self.math not in ('exact', 'fast'):
+            raise Exception("solver.math must be 'exact' or 'fast'")
+        cfg.math = 1 if self.math == 'fast' else 0
+        cfg.kind = 1
+        cfg.lim_type = int(self.lim_type)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().pcl_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self._stage = _StageState(state)
+        self.allocate_bc_arrays(state)
+        self._setup_halo(state)
+        if self.auxbc is not None:
+            _lib.check(_lib.lib().pcl_put_aux(self._h, _lib.d(_lib.fortran64(self.auxbc))))
+            if self._halo_active:
+                _lib.check(_lib.lib().pcl_halo_exchange_aux(self._h))
+
+    def _custom_bc(self, state, dim, idim, side, fn):
+        # Python custom BCs on a stage: same strip protocol as the base class, `state` carries stage time
+        super(SharpClawSolver, self)._custom_bc(state, dim, idim, side, fn)
+
+
+class SharpClawSolver1D(SharpClawSolver):
+    """SharpClaw solver for one-dimensional problems (sharpclaw.py:286-447)."""
+
+    def __init__(self, data=None):
+        self.ndim = 1
+        super(SharpClawSolver1D, self).__init__(data)
+
+
+class SharpClawSolver2D(SharpClawSolver):
+    """SharpClaw evolution routine in 2D (sharpclaw.py:452-563)."""
+
+    def __init__(self, data=None):
+        self.ndim = 2
+        super(SharpClawSolver2D, self).__init__(data)

@@ -38,9 +38,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from pyclaw_amd import _lib
     # ndim + n[3] + mbc + meqn,mwaves,maux + method[7] + mthlim[8] + fwave + rp = 25 ints (+4 pad),
-    # then 8 + 3 doubles, then device + math
+    # then 8 + 3 doubles, then device, math, kind, lim_type
     assert _lib.Config.rp_params.offset == 104
-    assert C.sizeof(_lib.Config) == 104 + 11 * 8 + 2 * 4
+    assert C.sizeof(_lib.Config) == 104 + 11 * 8 + 4 * 4
 
 
 def test_no_cpu_fallback():
