@@ -141,6 +141,8 @@ int pcl_put_aux(pcl_solver *s, const double *host_auxbc); /* always with ghosts 
  * (arbitrary user numpy code) or pcl_bc_const (inflow of a constant state). */
 int pcl_bc(pcl_solver *s, int idim, int side, int bctype);
 int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state /* [meqn] */);
+/* Same fill for the aux array (auxbc_lower/upper, solver.py:526-596: reflecting does not negate). */
+int pcl_bc_aux(pcl_solver *s, int idim, int side, int bctype);
 /* Copy the `width` outermost layers (ghost cells first) of one side to/from a host
  * array shaped like qbc with that dimension cut to `width`: for custom BCs written in
  * Python that only touch the strip (user_bc_lower/upper, solver.py:404-405,439-440). */

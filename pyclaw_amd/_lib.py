@@ -62,6 +62,7 @@ PROTOTYPES = {
     "pcl_put_aux": (C.c_int, [C.c_void_p, dp]),
     "pcl_bc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pcl_bc_const": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "pcl_bc_aux": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pcl_get_strip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]),
     "pcl_put_strip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]),
     "pcl_step_hyperbolic": (C.c_int, [C.c_void_p, C.c_double, dp]),

@@ -205,10 +205,7 @@ class ClawSolver(Solver):
 
         self.allocate_bc_arrays(state)
         self._setup_halo(state)
-        if self.auxbc is not None:
-            _lib.check(_lib.lib().pcl_put_aux(self._h, _lib.d(_lib.fortran64(self.auxbc))))
-            if self._halo_active:
-                _lib.check(_lib.lib().pcl_halo_exchange_aux(self._h))
+        self._upload_aux(state)
 
     def teardown(self):
         super(ClawSolver, self).teardown()

@@ -90,7 +90,7 @@ __global__ void soa_to_aos(const double *__restrict__ src, double *__restrict__ 
 // ---- ghost-cell fills, solver.py:384-452 ---------------------------------------------------
 // One thread per (transverse index t, ghost layer g, component m).
 __global__ void bc_kernel(double *q, int nm, int I, int J, long pitch, long plane, int mbc, int idim,
-                          int side, int type, const double *cstate) {
+                          int side, int type, const double *cstate, int is_aux) {
     const int nt = idim == 0 ? J : I;
     const int N = idim == 0 ? I : J;
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,12 +106,12 @@ __global__ void bc_kernel(double *q, int nm, int I, int J, long pitch, long plan
         dstk = g;
         if (type == PCL_BC_OUTFLOW) srck = mbc;
         else if (type == PCL_BC_PERIODIC) srck = N - 2 * mbc + g;
-        else { srck = 2 * mbc - 1 - g; if (type == PCL_BC_REFLECTING && m == idim + 1) sign = -1.0; }
+        else { srck = 2 * mbc - 1 - g; if (type == PCL_BC_REFLECTING && m == idim + 1 && !is_aux) sign = -1.0; }
     } else {
         dstk = N - 1 - g;
         if (type == PCL_BC_OUTFLOW) srck = N - mbc - 1;
         else if (type == PCL_BC_PERIODIC) srck = 2 * mbc - 1 - g;  // q[N-mbc+k] = q[mbc+k], k=mbc-1-g
-        else { srck = N - 2 * mbc + g; if (type == PCL_BC_REFLECTING && m == idim + 1) sign = -1.0; }
+        else { srck = N - 2 * mbc + g; if (type == PCL_BC_REFLECTING && m == idim + 1 && !is_aux) sign = -1.0; }
     }
     const long d = idim == 0 ? (long)t * pitch + dstk : (long)dstk * pitch + t;
     if (type == 100) {  // constant inflow state
@@ -491,11 +491,13 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
     return PCL_OK;
 }
 
-static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate) {
+static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate, bool aux = false) {
     const int nt = idim == 0 ? s->J : s->I;
-    const long n = (long)nt * s->cfg.mbc * s->cfg.meqn;
-    hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, cur(s),
-                       s->cfg.meqn, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, idim, side, type, cstate);
+    const int nm = aux ? s->cfg.maux : s->cfg.meqn;
+    const long n = (long)nt * s->cfg.mbc * nm;
+    hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream,
+                       aux ? s->aux : cur(s), nm, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, idim, side, type,
+                       cstate, aux ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
@@ -507,6 +509,16 @@ int pcl_bc(pcl_solver *s, int idim, int side, int bctype) {
         return fail(PCL_EINVAL, "pcl_bc: only outflow/periodic/reflecting run here");
     HIP_TRY(hipSetDevice(s->cfg.device));
     return bc_launch(s, idim, side, bctype, nullptr);
+}
+
+int pcl_bc_aux(pcl_solver *s, int idim, int side, int bctype) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.maux <= 0) return PCL_OK;
+    if (idim < 0 || idim >= s->cfg.ndim || side < 0 || side > 1) return fail(PCL_EINVAL, "bad idim/side");
+    if (bctype != PCL_BC_OUTFLOW && bctype != PCL_BC_PERIODIC && bctype != PCL_BC_REFLECTING)
+        return fail(PCL_EINVAL, "pcl_bc_aux: only outflow/periodic/reflecting run here");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    return bc_launch(s, idim, side, bctype, nullptr, true);
 }
 
 int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state) {

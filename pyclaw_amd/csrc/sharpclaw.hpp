@@ -45,16 +45,21 @@ __device__ __forceinline__ void weno5_pyweno(double qm2, double qm1, double q0, 
                           ((c833 * qm1) * qm1) + ((c1033 * qm1) * q0) + ((c333 * q0) * q0);
     const double t0 = sigma0 + eps, t1 = sigma1 + eps, t2 = sigma2 + eps;
     const double d0 = t0 * t0, d1 = t1 * t1, d2 = t2 * t2;
+    // 12 divisions, 5 distinct denominators (each (sigma+eps)^2 >= 1e-72 is used twice, each weight
+    // sum three times): shared-reciprocal quotients, the same correctly rounded values (rp.hpp).
+    const Recip by_d0(d0), by_d1(d1), by_d2(d2);
     double acc = 0.0;
-    double omega0 = fdiv_ieee(w01, d0); acc = acc + omega0;
-    double omega1 = fdiv_ieee(w06, d1); acc = acc + omega1;
-    double omega2 = fdiv_ieee(w03, d2); acc = acc + omega2;
-    omega0 = fdiv_ieee(omega0, acc); omega1 = fdiv_ieee(omega1, acc); omega2 = fdiv_ieee(omega2, acc);
+    double omega0 = by_d0.div(w01); acc = acc + omega0;
+    double omega1 = by_d1.div(w06); acc = acc + omega1;
+    double omega2 = by_d2.div(w03); acc = acc + omega2;
+    const Recip by_acc(acc);
+    omega0 = by_acc.div(omega0); omega1 = by_acc.div(omega1); omega2 = by_acc.div(omega2);
     acc = 0.0;
-    double omega3 = fdiv_ieee(w03, d0); acc = acc + omega3;
-    double omega4 = fdiv_ieee(w06, d1); acc = acc + omega4;
-    double omega5 = fdiv_ieee(w01, d2); acc = acc + omega5;
-    omega3 = fdiv_ieee(omega3, acc); omega4 = fdiv_ieee(omega4, acc); omega5 = fdiv_ieee(omega5, acc);
+    double omega3 = by_d0.div(w03); acc = acc + omega3;
+    double omega4 = by_d1.div(w06); acc = acc + omega4;
+    double omega5 = by_d2.div(w01); acc = acc + omega5;
+    const Recip by_acc2(acc);
+    omega3 = by_acc2.div(omega3); omega4 = by_acc2.div(omega4); omega5 = by_acc2.div(omega5);
     const double fr0 = f183 * q0 + f116 * qp1 + f033 * qp2;
     const double fr1 = f033 * qm1 + f083 * q0 + f016 * qp1;
     const double fr2 = f016 * qm2 + f083 * qm1 + f033 * q0;

@@ -232,10 +232,7 @@ class SharpClawSolver(Solver):
         self._stage = _StageState(state)
         self.allocate_bc_arrays(state)
         self._setup_halo(state)
-        if self.auxbc is not None:
-            _lib.check(_lib.lib().pcl_put_aux(self._h, _lib.d(_lib.fortran64(self.auxbc))))
-            if self._halo_active:
-                _lib.check(_lib.lib().pcl_halo_exchange_aux(self._h))
+        self._upload_aux(state)
 
     def _custom_bc(self, state, dim, idim, side, fn):
         # Python custom BCs on a stage: same strip protocol as the base class, `state` carries stage time

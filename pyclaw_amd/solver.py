@@ -263,6 +263,30 @@ class Solver(object):
                     else:
                         raise NotImplementedError("Boundary condition %s not implemented" % bc)
 
+    def _upload_aux(self, state):
+        """auxbc -> HBM.  Decomposed runs: exchange the aux halo, then redo the physical aux BCs on
+        the device so that corner ghost cells next to a neighbour face are right (the reference
+        order: globalToLocal, then auxbc_lower/upper; solver.py:492-523)."""
+        if self.auxbc is None:
+            return
+        L = _lib.lib()
+        _lib.check(L.pcl_put_aux(self._h, _lib.d(_lib.fortran64(self.auxbc))))
+        if not self._halo_active:
+            return
+        _lib.check(L.pcl_halo_exchange_aux(self._h))
+        for idim, dim in enumerate(state.grid.dimensions):
+            whole = self._at_lower(dim) and self._at_upper(dim)
+            for side, at_edge, bcs in ((0, self._at_lower(dim), self.aux_bc_lower),
+                                       (1, self._at_upper(dim), self.aux_bc_upper)):
+                if not at_edge:
+                    continue
+                bc = bcs[idim]
+                if bc == BC.custom:
+                    raise NotImplementedError("custom aux BCs are not supported on a decomposed grid")
+                if bc == BC.periodic and not whole:
+                    continue
+                _lib.check(L.pcl_bc_aux(self._h, idim, side, bc))
+
     # ------------------------------------------------------------------ multi-GPU glue
     _halo_active = False
 
