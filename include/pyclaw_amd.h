@@ -153,7 +153,8 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
  * dim-split  = step2ds(ids=1) then step2ds(ids=2)          clawpack.py:538-546
  * unsplit    = step2                                       clawpack.py:550-552
  * 1-D        = step1                                       clawpack.py:323
- * *cfl receives the max Courant number (local to this process).  The pre-step state
+ * *cfl receives the max Courant number -- over all blocks once pcl_comm_init has been called (the
+ * all-reduce of petclaw/cfl.py:29-31 runs on the device before the read-back).  The pre-step state
  * stays available until the next call: pcl_undo_step() makes it current again (the
  * reference's q_backup / retake path, solver.py:660,690) without any copy. */
 int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl);
@@ -177,7 +178,8 @@ int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int npar
  * their ghost cells filled exactly like q (apply_q_bcs(stage), sharpclaw.py:546). */
 int pcl_select(pcl_solver *s, int reg);
 /* sharpclaw1.flux1 / sharpclaw2.flux2 (sharpclaw.py:385,558; flux1.f90, flux2.f90): dq register :=
- * dt * dq/dt of the selected register (ghost cells must be filled); *cfl = local max Courant number. */
+ * dt * dq/dt of the selected register (ghost cells must be filled); *cfl = max Courant number (global
+ * after pcl_comm_init). */
 int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl);
 /* Register arithmetic of the Runge-Kutta schemes (sharpclaw.py:168-206), evaluated in the order
  * written: op 1: D = A + B/ca   2: D = ca*A + cb*(B + C)   3: D = A/ca + cb*B

@@ -154,6 +154,15 @@ public:
         return 0;
     }
 
+    // in-place max all-reduce of one double that already lives on the device (the CFL word),
+    // enqueued on the solver stream: no extra host round trip
+    int allreduce_max_device(double *dev, std::string &err) {
+        if (!active) return 0;
+        ncclResult_t r = api().ncclAllReduce(dev, dev, 1, ncclDouble, ncclMax, comm_, stream_);
+        if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + api().ncclGetErrorString(r); return -1; }
+        return 0;
+    }
+
     int allreduce_max(double *v, std::string &err) {
         if (!active) { err = "allreduce before pcl_comm_init"; return -1; }
         Api &a = api();

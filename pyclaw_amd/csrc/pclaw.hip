@@ -275,7 +275,13 @@ int do_unsplit(pcl_solver *s, double dt) {
     return PCL_OK;
 }
 
+// The step's Courant number: in a decomposed run the max over all blocks (petclaw/cfl.py:29-31),
+// reduced on the device before the single 8-byte read-back.
 int read_cfl(pcl_solver *s, double *cfl) {
+    if (s->halo.active) {
+        std::string err;
+        if (s->halo.allreduce_max_device(reinterpret_cast<double *>(s->cfl_dev), err)) return fail(PCL_ECOMM, err);
+    }
     HIP_TRY(hipMemcpyAsync(s->cfl_host, s->cfl_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));

@@ -307,13 +307,9 @@ class Solver(object):
         nbr = np.array(dec.neighbors(periodic), dtype=np.int32)
         _lib.check(L.pcl_comm_init(self._h, parallel.world_size(), parallel.rank(), uid, _lib.i(nbr)))
         self._halo_active = True
-        import ctypes
-
-        def reduce_max(v):
-            box = ctypes.c_double(v)
-            _lib.check(L.pcl_allreduce_max(self._h, ctypes.cast(ctypes.byref(box), _lib.dp)))
-            return box.value
-        self.cfl._reduce = reduce_max
+        # the CFL all-reduce (petclaw/cfl.py:29-31) happens inside pcl_step_hyperbolic /
+        # pcl_sharp_dq on the device: the value they return is already the global maximum
+        self.cfl._reduce = None
 
     # ------------------------------------------------------------------ evolution
     def evolve_to_time(self, solution, tend=None):

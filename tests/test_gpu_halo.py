@@ -85,3 +85,36 @@ def test_partial_neighbours():
         assert np.array_equal(out, expect)
     finally:
         lib.pcl_destroy(h)
+
+
+def test_step_with_comm_single_rank():
+    """pcl_step_hyperbolic on a solver that joined a (1-rank) communicator: the device-side CFL
+    all-reduce must leave the step and its Courant number unchanged."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    mx, my, g = 64, 40, 2
+    rng = np.random.default_rng(3)
+    qbc = np.empty((5, mx + 2 * g, my + 2 * g), order="F")
+    qbc[0] = 1 + 0.1 * rng.random(qbc.shape[1:])
+    qbc[1] = 0.1 * rng.random(qbc.shape[1:])
+    qbc[2] = 0.05 * rng.random(qbc.shape[1:])
+    qbc[3] = 2.5 + 0.1 * rng.random(qbc.shape[1:])
+    qbc[4] = rng.random(qbc.shape[1:])
+    res = []
+    for with_comm in (False, True):
+        h = make_solver(L, mx, my)
+        try:
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                nbr = np.full(8, -1, dtype=np.int32)
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(nbr)))
+            L.check(lib.pcl_put_q(h, L.d(qbc), 1))
+            cfl = C.c_double()
+            L.check(lib.pcl_step_hyperbolic(h, 1e-3, C.cast(C.byref(cfl), L.dp)))
+            out = np.zeros_like(qbc)
+            L.check(lib.pcl_get_q(h, L.d(out), 1))
+            res.append((out, cfl.value))
+        finally:
+            lib.pcl_destroy(h)
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and res[0][1] > 0
