@@ -159,6 +159,13 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
  * reference's q_backup / retake path, solver.py:660,690) without any copy. */
 int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl);
 int pcl_undo_step(pcl_solver *s);
+/* apply_q_bcs + step_hyperbolic in ONE call (clawpack.py:528-555 with solver.py:354-381): the ghost
+ * fills of the listed sides, in the reference's order (dimension by dimension, lower then upper),
+ * then the step.  bc[2*idim+side] = PCL_BC_OUTFLOW/PERIODIC/REFLECTING, PCL_BC_CUSTOM with
+ * cstate[(2*idim+side)*PCL_MAX_RP_PARAMS ...] = constant state, or -1 = leave that side alone (not at a
+ * physical boundary / periodic handled by the halo).  Does the halo exchange first when pcl_comm_init
+ * has been called. */
+int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, double *cfl);
 /* Single directional sweep (ids = 1 or 2), qold -> qnew like step2ds; used by layer 1. */
 int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl);
 

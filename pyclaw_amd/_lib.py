@@ -67,6 +67,7 @@ PROTOTYPES = {
     "pcl_put_strip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]),
     "pcl_step_hyperbolic": (C.c_int, [C.c_void_p, C.c_double, dp]),
     "pcl_undo_step": (C.c_int, [C.c_void_p]),
+    "pcl_bc_step": (C.c_int, [C.c_void_p, ip, dp, C.c_double, dp]),
     "pcl_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_double, dp]),
     "pcl_backup": (C.c_int, [C.c_void_p]),
     "pcl_restore": (C.c_int, [C.c_void_p]),

@@ -118,9 +118,15 @@ class ClawSolver(Solver):
         r"""One homogeneous step on the resident state (clawpack.py:299-323,510-555)."""
         import ctypes
         state = solution.states[0]
-        self.apply_q_bcs(state)
         cfl = ctypes.c_double(0.0)
-        _lib.check(_lib.lib().pcl_step_hyperbolic(self._h, self.dt, ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+        spec = self._device_bc_spec(state)
+        if spec is not None:
+            # every ghost fill runs on the device: BCs + step in one library call
+            _lib.check(_lib.lib().pcl_bc_step(self._h, _lib.i(spec[0]), _lib.d(spec[1]), self.dt,
+                                              ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+        else:
+            self.apply_q_bcs(state)
+            _lib.check(_lib.lib().pcl_step_hyperbolic(self._h, self.dt, ctypes.cast(ctypes.byref(cfl), _lib.dp)))
         self._host_stale = True
         self.cfl.update_global_max(cfl.value)
 

@@ -274,6 +274,28 @@ template <int IXY> struct TileShape {
 };
 constexpr int LINE = 16;  // doubles per 128-byte line
 
+// Boundary condition of one side as an index remap (solver.py:384-452): ghost index k of a dimension
+// with n cells (ghosts included) reads interior index `src`; `neg` = reflecting (negate the normal
+// momentum component), `cst` = constant inflow state.
+struct VbcMap { int src; bool neg, cst; int side; };
+__device__ __forceinline__ VbcMap vbc_map(int k, int n, int mbc, int lo, int hi) {
+    VbcMap r{k, false, false, 0};
+    if (k < mbc && lo >= 0) {
+        r.side = 0;
+        if (lo == 1) r.src = mbc;                       // outflow
+        else if (lo == 2) r.src = n - 2 * mbc + k;      // periodic
+        else if (lo == 3) { r.src = 2 * mbc - 1 - k; r.neg = true; }
+        else r.cst = true;
+    } else if (k >= n - mbc && hi >= 0) {
+        r.side = 1;
+        if (hi == 1) r.src = n - mbc - 1;
+        else if (hi == 2) r.src = k - (n - 2 * mbc);    // q[n-mbc+t] = q[mbc+t]
+        else if (hi == 3) { r.src = 2 * (n - mbc) - 1 - k; r.neg = true; }
+        else r.cst = true;
+    }
+    return r;
+}
+
 template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = false>
 __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     using T = TileShape<IXY>;
@@ -301,14 +323,46 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
         if (al < T::ALONG) {
             int ga = a0 + al;
             ga = ga < n_along ? ga : n_along - 1;  // clamp: cells past the edge repeat the last one
+            // only tiles that touch the ghost frame take the remap path (workgroup-uniform): the plain
+            // path keeps its 20 loads per thread independent and in flight together
+            const bool vb = !TRANS && a.vbc_on &&
+                            (a0 < a.mbc || a0 + T::ALONG > n_along - a.mbc || b0 < a.mbc ||
+                             b0 + T::ACROSS > n_across - a.mbc || DIM1);
+            if (!vb) {  // one basic block: all 20 loads issue before the first LDS write waits
 #pragma unroll
-            for (int ac = 0; ac < T::ACROSS; ac++) {
-                int gb = b0 + ac;
-                gb = gb < n_across ? gb : n_across - 1;
-                const long g = (long)gb * a.pitch + ga;
+                for (int ac = 0; ac < T::ACROSS; ac++) {
+                    int gb = b0 + ac;
+                    gb = gb < n_across ? gb : n_across - 1;
+                    const long g = (long)gb * a.pitch + ga;
 #pragma unroll
-                for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = a.qin[m * a.plane + g];
-                if constexpr (CAPA) tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
+                    for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = a.qin[m * a.plane + g];
+                    if constexpr (CAPA) tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
+                }
+            } else {
+                // qbc = Y(X(q)): x sides first, then y sides over the x-filled array (solver.py:354-381)
+                const VbcMap mi = vbc_map(ga, n_along, a.mbc, a.vbc[0], a.vbc[1]);
+#pragma unroll
+                for (int ac = 0; ac < T::ACROSS; ac++) {
+                    int gb = b0 + ac;
+                    gb = gb < n_across ? gb : n_across - 1;
+                    const VbcMap mj = DIM1 ? VbcMap{gb, false, false, 0}
+                                           : vbc_map(gb, n_across, a.mbc, a.vbc[2], a.vbc[3]);
+                    const long gs = (long)mj.src * a.pitch + mi.src;
+                    // branch-free: every lane loads (its own cell or the BC's source cell), then selects
+#pragma unroll
+                    for (int m = 0; m < MEQN; m++) {
+                        double v = a.qin[m * a.plane + gs];
+                        if (m == 1) v = mi.neg ? -v : v;
+                        const double cx = mi.side ? a.vconst[1][m] : a.vconst[0][m];
+                        v = mi.cst ? cx : v;
+                        if (m == 2) v = mj.neg ? -v : v;
+                        const double cy = mj.side ? a.vconst[3][m] : a.vconst[2][m];
+                        v = mj.cst ? cy : v;
+                        tile[T::at(m, al, ac)] = v;
+                    }
+                    if constexpr (CAPA)
+                        tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + (long)gb * a.pitch + ga];
+                }
             }
         }
     } else {

@@ -47,9 +47,12 @@ struct pcl_solver {
     unsigned long long *cfl_dev = nullptr;
     unsigned long long *cfl_host = nullptr;  // pinned
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_cfl = nullptr;
     double **undo_slot = nullptr;  // buffer that holds the pre-step state
     bool timing = false;
+    int vbc_on = 0;       // next x pass evaluates these BCs while loading (pcl_bc_step)
+    int vbc[4] = {-1, -1, -1, -1};
+    double vconst[4][8] = {};
     struct Timed { hipEvent_t a, b; int which; };
     std::vector<Timed> timed;
     std::vector<hipEvent_t> evpool;
@@ -90,7 +93,7 @@ __global__ void soa_to_aos(const double *__restrict__ src, double *__restrict__ 
 // ---- ghost-cell fills, solver.py:384-452 ---------------------------------------------------
 // One thread per (transverse index t, ghost layer g, component m).
 __global__ void bc_kernel(double *q, int nm, int I, int J, long pitch, long plane, int mbc, int idim,
-                          int side, int type, const double *cstate, int is_aux) {
+                          int side, int type, pcl::RpParams cstate, int is_aux) {
     const int nt = idim == 0 ? J : I;
     const int N = idim == 0 ? I : J;
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,7 +118,7 @@ __global__ void bc_kernel(double *q, int nm, int I, int J, long pitch, long plan
     }
     const long d = idim == 0 ? (long)t * pitch + dstk : (long)dstk * pitch + t;
     if (type == 100) {  // constant inflow state
-        q[m * plane + d] = cstate[m];
+        q[m * plane + d] = cstate.v[m];
         return;
     }
     const long s = idim == 0 ? (long)t * pitch + srck : (long)srck * pitch + t;
@@ -175,6 +178,8 @@ SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, dou
     a.dtd = dt / s->cfg.d[ids - 1];
     for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) a.par.v[k] = s->cfg.rp_params[k];
     a.cfl = s->cfl_dev;
+    a.vbc_on = (ids == 1) ? s->vbc_on : 0;
+    for (int k = 0; k < 4; k++) { a.vbc[k] = s->vbc[k]; for (int m = 0; m < 8; m++) a.vconst[k][m] = s->vconst[k][m]; }
     static const int ablate = [] { const char *e = getenv("PCL_TUNE_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
     return a;
@@ -275,6 +280,12 @@ int do_unsplit(pcl_solver *s, double dt) {
     return PCL_OK;
 }
 
+// a failed step must not leave a partial maximum behind (see read_cfl's invariant)
+int bail(pcl_solver *s, int rc) {
+    (void)hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream);
+    return rc;
+}
+
 // The step's Courant number: in a decomposed run the max over all blocks (petclaw/cfl.py:29-31),
 // reduced on the device before the single 8-byte read-back.
 int read_cfl(pcl_solver *s, double *cfl) {
@@ -284,7 +295,11 @@ int read_cfl(pcl_solver *s, double *cfl) {
     }
     HIP_TRY(hipMemcpyAsync(s->cfl_host, s->cfl_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipEventRecord(s->ev_cfl, s->stream));
+    // Invariant: the CFL word is zero whenever no step is in flight.  Re-zeroing it here, behind the
+    // read-back, keeps the reset off the critical path (the host only waits for the copy).
+    HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
+    HIP_TRY(hipEventSynchronize(s->ev_cfl));
     double v;
     memcpy(&v, s->cfl_host, sizeof(double));
     *cfl = v;
@@ -375,6 +390,8 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->cfl_host, 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_cfl, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMemsetAsync(s->cfl_dev, 0, 64, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) {
         std::string msg = std::string("pcl_create: ") + hipGetErrorString(e);
@@ -402,6 +419,7 @@ void pcl_destroy(pcl_solver *s) {
     if (s->cfl_host) hipHostFree(s->cfl_host);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->ev_cfl) hipEventDestroy(s->ev_cfl);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
 }
@@ -498,12 +516,14 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
 }
 
 static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate, bool aux = false) {
+    pcl::RpParams cs;  // the constant state travels as a kernel argument: no copy, no sync
+    for (int k = 0; k < 8; k++) cs.v[k] = (cstate && k < s->cfg.meqn) ? cstate[k] : 0.0;
     const int nt = idim == 0 ? s->J : s->I;
     const int nm = aux ? s->cfg.maux : s->cfg.meqn;
     const long n = (long)nt * s->cfg.mbc * nm;
     hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream,
                        aux ? s->aux : cur(s), nm, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, idim, side, type,
-                       cstate, aux ? 1 : 0);
+                       cs, aux ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
@@ -531,11 +551,8 @@ int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state) {
     if (!s || !state) return fail(PCL_EINVAL, "null argument");
     if (idim < 0 || idim >= s->cfg.ndim || side < 0 || side > 1) return fail(PCL_EINVAL, "bad idim/side");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    // constants travel through the pinned cfl page's tail? no: a tiny device scratch at stage head
-    HIP_TRY(hipMemcpyAsync(s->stage, state, sizeof(double) * s->cfg.meqn, hipMemcpyHostToDevice,
-                           s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));  // `state` may be a temporary
-    return bc_launch(s, idim, side, 100, s->stage);
+    if (s->cfg.meqn > 8) return fail(PCL_EINVAL, "constant-state BC supports meqn <= 8");
+    return bc_launch(s, idim, side, 100, state);
 }
 
 int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl) {
@@ -543,8 +560,7 @@ int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl) {
     if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     if (ids < 1 || ids > s->cfg.ndim) return fail(PCL_EINVAL, "bad ids");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
-    if (int rc = do_sweep(s, s->q, s->t1, ids, dt)) return rc;
+    if (int rc = do_sweep(s, s->q, s->t1, ids, dt)) return bail(s, rc);
     std::swap(s->q, s->t1);
     s->undo_slot = &s->t1;
     return read_cfl(s, cfl);
@@ -554,22 +570,61 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
     if (s->cfg.ndim == 1) {
-        if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return rc;
+        if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return bail(s, rc);
         std::swap(s->q, s->t1);
         s->undo_slot = &s->t1;
     } else if (s->cfg.method[2] < 0) {  // dimensional splitting, clawpack.py:538-546
-        if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return rc;
-        if (int rc = do_sweep(s, s->t1, s->t2, 2, dt)) return rc;
+        if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return bail(s, rc);
+        if (int rc = do_sweep(s, s->t1, s->t2, 2, dt)) return bail(s, rc);
         std::swap(s->q, s->t2);
         s->undo_slot = &s->t2;
     } else {  // unsplit, clawpack.py:550-552 -> step2.f
-        if (int rc = do_unsplit(s, dt)) return rc;
+        if (int rc = do_unsplit(s, dt)) return bail(s, rc);
         std::swap(s->q, s->t1);
         s->undo_slot = &s->t1;
     }
     return read_cfl(s, cfl);
+}
+
+int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, double *cfl) {
+    if (!s || !bc || !cfl) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    if (s->halo.active) {
+        std::string err;
+        if (s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);
+    }
+    for (int k = 0; k < 2 * s->cfg.ndim; k++) {
+        const int t = bc[k];
+        if (t >= 0 && t != PCL_BC_CUSTOM && t != PCL_BC_OUTFLOW && t != PCL_BC_PERIODIC && t != PCL_BC_REFLECTING)
+            return fail(PCL_EINVAL, "bad boundary condition type");
+        if (t == PCL_BC_CUSTOM && !cstate) return fail(PCL_EINVAL, "constant state missing");
+    }
+    // Dimension-split steps (and 1-D): the first pass evaluates the boundary conditions while it
+    // loads its tiles -- no ghost-fill launches (each costs ~5 us of launch latency per step).
+    const bool fused = s->cfg.meqn <= 8 && (s->cfg.ndim == 1 || s->cfg.method[2] < 0);
+    if (fused) {
+        for (int k = 0; k < 4; k++) {
+            s->vbc[k] = k < 2 * s->cfg.ndim ? bc[k] : -1;
+            for (int m = 0; m < 8; m++)
+                s->vconst[k][m] = (s->vbc[k] == PCL_BC_CUSTOM) ? cstate[k * PCL_MAX_RP_PARAMS + m] : 0.0;
+        }
+        s->vbc_on = 1;
+        const int rc = pcl_step_hyperbolic(s, dt, cfl);
+        s->vbc_on = 0;
+        return rc;
+    }
+    for (int idim = 0; idim < s->cfg.ndim; idim++)
+        for (int side = 0; side < 2; side++) {
+            const int t = bc[2 * idim + side];
+            if (t < 0) continue;
+            const int rc = t == PCL_BC_CUSTOM
+                               ? bc_launch(s, idim, side, 100, cstate + (2 * idim + side) * PCL_MAX_RP_PARAMS)
+                               : bc_launch(s, idim, side, t, nullptr);
+            if (rc) return rc;
+        }
+    return pcl_step_hyperbolic(s, dt, cfl);
 }
 
 int pcl_undo_step(pcl_solver *s) {
@@ -631,7 +686,6 @@ int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl) {
     if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_ESTATE, "SharpClaw call on a classic solver");
     if (s->sel == PCL_REG_DQ) return fail(PCL_EINVAL, "dq of the dq register");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    HIP_TRY(hipMemsetAsync(s->cfl_dev, 0, sizeof(unsigned long long), s->stream));
     std::string err;
     for (int ids = 1; ids <= s->cfg.ndim; ids++) {
         SweepLaunch l;
@@ -642,7 +696,7 @@ int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl) {
         if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; hipEventRecord(t.a, s->stream); }
         int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sharp(l, err) : pcl::exact::launch_sharp(l, err);
         if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
-        if (rc) return fail(rc, err);
+        if (rc) return bail(s, fail(rc, err));
     }
     return read_cfl(s, cfl);
 }

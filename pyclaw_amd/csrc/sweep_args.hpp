@@ -28,6 +28,12 @@ struct SweepArgs {
     RpParams par;
     unsigned long long *cfl;  // device word holding the running max (as ordered bits)
     int ablate;       // diagnostic only (tools/kbench.py): bit0 = skip the arithmetic (copy through)
+    // "virtual ghost cells": the x pass of the dim-split step evaluates the boundary conditions while it
+    // loads (a ghost cell is an index remap of an interior cell, or a constant): no ghost-fill launches.
+    // vbc[2*idim+side] = -1 (read memory) | PCL_BC_OUTFLOW | PERIODIC | REFLECTING | PCL_BC_CUSTOM (= vconst)
+    int vbc_on;
+    int vbc[4];
+    double vconst[4][8];
     // unsplit algorithm (step2.f) only:
     int trans;        // method(3): 0 no transverse terms, 1 increment waves, 2 + correction waves
     double dtd_t;     // dt/d of the transverse direction

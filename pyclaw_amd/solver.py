@@ -199,6 +199,41 @@ class Solver(object):
                 else:
                     raise NotImplementedError("Boundary condition %s not implemented" % bc)
 
+    def _device_bc_spec(self, state):
+        """(types[2*ndim], constant states) for pcl_bc_step when every ghost fill of apply_q_bcs can
+        run on the device (no plain-Python callback), else None.  Cached per solver setup."""
+        key = (tuple(self.bc_lower), tuple(self.bc_upper), id(self.user_bc_lower), id(self.user_bc_upper))
+        cached = getattr(self, '_bc_spec_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        types = np.full(2 * self.ndim, -1, dtype=np.int32)
+        consts = np.zeros(2 * self.ndim * _lib.MAX_RP_PARAMS)
+        spec = (types, consts)
+        for idim, dim in enumerate(state.grid.dimensions):
+            whole = self._at_lower(dim) and self._at_upper(dim)
+            for side, at_edge, bcs, fn in ((0, self._at_lower(dim), self.bc_lower, self.user_bc_lower),
+                                           (1, self._at_upper(dim), self.bc_upper, self.user_bc_upper)):
+                if not at_edge:
+                    continue
+                bc = bcs[idim]
+                k = 2 * idim + side
+                if bc == BC.custom:
+                    if isinstance(fn, ConstantStateBC) and state.meqn <= _lib.MAX_RP_PARAMS:
+                        if fn.dims is None or idim in fn.dims:
+                            types[k] = BC.custom
+                            consts[k * _lib.MAX_RP_PARAMS:k * _lib.MAX_RP_PARAMS + state.meqn] = fn.state
+                    else:
+                        spec = None
+                elif bc == BC.periodic:
+                    if whole:
+                        types[k] = bc
+                elif bc in (BC.outflow, BC.reflecting):
+                    types[k] = bc
+                else:
+                    spec = None
+        self._bc_spec_cache = (key, spec)
+        return spec
+
     def _custom_bc(self, state, dim, idim, side, fn):
         if fn is None:
             raise Exception("Custom BC requested but user_bc_%s is not set" % ("lower", "upper")[side])
