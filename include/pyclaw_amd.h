@@ -125,6 +125,18 @@ int pcl_step2(int rp, const double *rp_params, int fwave, int meqn, int mwaves, 
               double dx, double dy, double dt, const int *method, const int *mthlim,
               double *cfl);
 
+/* sharpclaw1.flux1(q,aux,dt,t,ixy,mx,mbc,maxnx) -> (dq,cfl)   1d/sharpclaw/flux1.f90, sharpclaw.py:385
+ * sharpclaw2.flux2(q,aux,dt,t,mbc,maxm,mx,my)   -> (dq,cfl)   2d/sharpclaw/flux2.f90:2, sharpclaw.py:558
+ * q and dq are (meqn, mx+2mbc[, my+2mbc]) with mbc = 3 (weno_order 5); dq's interior receives
+ * dt*dq/dt, its ghost cells are zeroed.  The F90 module state the reference sets through
+ * clawparams/workspace/reconstruct (lim_type, mcapa, dx, mwaves) is passed explicitly. */
+int pcl_sharp_flux1(int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux, int mcapa,
+                    int mbc, int mx, const double *q, double *dq, const double *aux, double dx, double dt,
+                    double *cfl);
+int pcl_sharp_flux2(int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux, int mcapa,
+                    int mbc, int mx, int my, const double *q, double *dq, const double *aux, double dx,
+                    double dy, double dt, double *cfl);
+
 /* ---- layer 2: resident solver -------------------------------------------------------- */
 int pcl_create(const pcl_config *cfg, pcl_solver **out);
 void pcl_destroy(pcl_solver *s);

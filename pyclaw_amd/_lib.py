@@ -55,6 +55,10 @@ PROTOTYPES = {
                               C.c_int]),
     "pcl_step2": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_double, ip, ip, dp]),
+    "pcl_sharp_flux1": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  dp, dp, dp, C.c_double, C.c_double, dp]),
+    "pcl_sharp_flux2": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_double, dp]),
     "pcl_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "pcl_destroy": (None, [C.c_void_p]),
     "pcl_put_q": (C.c_int, [C.c_void_p, dp, C.c_int]),

@@ -121,7 +121,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
     RP::template solve<IXY>(cL, cR, a.par, wave, s, amdq, apdq);
 
     // Courant number, flux2.f:109-117
-    if (cfl_ok) {
+    if (cfl_ok && !(a.ablate & 8)) {
 #pragma unroll
         for (int mw = 0; mw < MWAVES; mw++)
             cflmax = dmax(dmax(cflmax, dtdx_c * s[mw]), -dtdx_l * s[mw]);
@@ -131,21 +131,33 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
 #pragma unroll
     for (int m = 0; m < MEQN; m++) { fadd[m] = 0.0; cq[m] = 0.0; }
 
-    if (a.order != 1) {
-        // limiter.f:33-57 -- dotl(i) = w(i-1).w(i) here, dotr(i) = dotl(i+1) from the right lane
+    if (a.order != 1 && !(a.ablate & 4)) {
+        // limiter.f:33-57 -- dotl(i) = w(i-1).w(i) here, dotr(i) = dotl(i+1) from the right lane.
+        // The reference skips an interface whose wave has zero norm (limiter.f:45); when NO lane of the
+        // wavefront has a wave in this family (a tracer-free or shear-free stretch, undisturbed gas) the
+        // neighbour shifts and dot products are skipped as well (nothing would be limited).
 #pragma unroll
         for (int mw = 0; mw < MWAVES; mw++) {
             const int lim = a.mthlim[mw];
-            if (lim == 0) continue;
-            // (the Fortran starts both sums at 0.d0; 0 + x == x up to the sign of a zero)
-            double wn = 0.0, dl = 0.0;
+            if (lim == 0 || (a.ablate & 2)) continue;
+            double wn = 0.0;
             bool first = true;
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
                 if (!RP::template nz<IXY>(mw, m)) continue;
                 const double w = wave[mw][m];
+                wn = first ? w * w : wn + w * w;   // (the Fortran starts the sum at 0.d0: same value)
+                first = false;
+            }
+            // lane 0 has no left cell (its 'wave' is garbage): it must not keep the family alive
+            if (!__any(wn != 0.0 && (threadIdx.x & (WAVE - 1)) != 0)) continue;  // wave-uniform
+            double dl = 0.0;
+            first = true;
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                if (!RP::template nz<IXY>(mw, m)) continue;
+                const double w = wave[mw][m];
                 const double wl = from_left(w);
-                wn = first ? w * w : wn + w * w;
                 dl = first ? wl * w : dl + wl * w;
                 first = false;
             }

@@ -816,6 +816,40 @@ int pcl_step2(int rp, const double *rp_params, int fwave, int meqn, int mwaves, 
                       dt, method, mthlim, cfl, 0, true);
 }
 
+static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux,
+                      int mcapa, int mbc, int mx, int my, const double *q, double *dq, const double *aux,
+                      double dx, double dy, double dt, double *cfl) {
+    if (!q || !dq || !cfl) return fail(PCL_EINVAL, "null argument");
+    pcl_config c;
+    memset(&c, 0, sizeof(c));
+    c.ndim = ndim; c.n[0] = mx; c.n[1] = my; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves; c.maux = maux;
+    c.method[1] = 2; c.method[5] = mcapa; c.method[6] = maux;
+    c.rp = rp;
+    if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
+    c.d[0] = dx; c.d[1] = dy; c.kind = PCL_KIND_SHARPCLAW; c.lim_type = lim_type; c.math = PCL_MATH_EXACT;
+    pcl_solver *s = nullptr;
+    if (int rc = pcl_create(&c, &s)) return rc;
+    int rc = pcl_put_q(s, q, 1);
+    if (!rc && maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
+    if (!rc) rc = pcl_sharp_dq(s, dt, cfl);
+    if (!rc) rc = pcl_select(s, PCL_REG_DQ);
+    if (!rc) rc = pcl_get_q(s, dq, 1);
+    pcl_destroy(s);
+    return rc;
+}
+
+int pcl_sharp_flux1(int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux, int mcapa,
+                    int mbc, int mx, const double *q, double *dq, const double *aux, double dx, double dt,
+                    double *cfl) {
+    return host_sharp(1, rp, rp_params, lim_type, meqn, mwaves, maux, mcapa, mbc, mx, 1, q, dq, aux, dx, 1.0, dt, cfl);
+}
+
+int pcl_sharp_flux2(int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux, int mcapa,
+                    int mbc, int mx, int my, const double *q, double *dq, const double *aux, double dx,
+                    double dy, double dt, double *cfl) {
+    return host_sharp(2, rp, rp_params, lim_type, meqn, mwaves, maux, mcapa, mbc, mx, my, q, dq, aux, dx, dy, dt, cfl);
+}
+
 // ---- multi-GPU -----------------------------------------------------------------------------------
 int pcl_comm_unique_id(char uid[128]) {
     std::string err;

@@ -61,6 +61,13 @@ def local_rank():
     return int(os.environ.get("LOCAL_RANK", str(rank())))
 
 
+def device_ordinal():
+    """HIP device of this rank: LOCAL_RANK, unless PCL_FORCE_DEVICE pins every rank to one ordinal
+    (diagnostics on a single-GPU box)."""
+    forced = os.environ.get("PCL_FORCE_DEVICE")
+    return int(forced) if forced is not None else local_rank()
+
+
 def barrier():
     if _state["dist"] is not None:
         _state["dist"].barrier()

@@ -220,7 +220,7 @@ class SharpClawSolver(Solver):
         for k, v in enumerate(params):
             cfg.rp_params[k] = v
         from . import parallel
-        cfg.device = parallel.local_rank() if state.decomp is not None else int(getattr(self, 'device', 0))
+        cfg.device = parallel.device_ordinal() if state.decomp is not None else int(getattr(self, 'device', 0))
         if self.math not in ('exact', 'fast'):
             raise Exception("solver.math must be 'exact' or 'fast'")
         cfg.math = 1 if self.math == 'fast' else 0

@@ -156,3 +156,21 @@ def test_sharpclaw_fast_math(coracle):
     D.run(p, coracle, 0.12, 10)
     q = claw.frames[claw.nout].state.q
     assert np.max(np.abs(q - p.q)) < 1e-12 * np.abs(p.q).max()
+
+
+def test_f2py_shaped_flux2(coracle):
+    """layer-1 entry point pcl_sharp_flux2 on host arrays == oracle flux2"""
+    from pyclaw_amd import _lib as L
+    rng = np.random.default_rng(77)
+    mx, my, mbc = 45, 31, 3
+    q = euler_q(rng, (mx + 2 * mbc, my + 2 * mbc))
+    par = np.array([1.4, 0.4, 0, 0, 0, 0, 0, 0.])
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.01
+    ref, cfl_ref = coracle.sharp_flux2(O.RP_EULER5_2D, par[:2], 2, 5, 0, mbc, mx, my, q, None, dx, dy, dt)
+    dq = np.zeros_like(q)
+    cfl = C.c_double()
+    L.check(L.lib().pcl_sharp_flux2(11, L.d(par), 2, 5, 5, 0, 0, mbc, mx, my, L.d(q), L.d(dq), None, dx, dy, dt,
+                                    C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
+    assert np.array_equal(dq[inner], ref[inner]) and cfl.value == cfl_ref
+    assert np.count_nonzero(dq[:, :mbc]) == 0
