@@ -34,13 +34,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_CELL_SWEEP = 2 * 5 * 8   # read + write of q (5 doubles) per directional pass
 
 
-def build(nx_global, ny_global, math):
+def build(nx_global, ny_global, math, unsplit=False):
     import pyclaw_amd as pyclaw
     from apps import problems
     # dt_initial scaled with dx like the reference test (0.005 at dx=1/80) -> first CFL ~ 0.4-0.5
     dt0 = 0.005 * (2.0 / nx_global) / (2.0 / 160.0)
     claw = problems.shockbubble(pyclaw, mx=nx_global, my=ny_global, device_callbacks=True,
-                                with_src=False, dt_initial=dt0, run=False, math=math)
+                                with_src=False, dt_initial=dt0, run=False, math=math,
+                                dim_split=not unsplit, order_trans=2)
     return claw
 
 
@@ -103,6 +104,7 @@ def main():
     ap.add_argument("--ny", type=int, default=4096, help="cells per GPU block in y")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--unsplit", action="store_true", help="unsplit algorithm with order_trans=2 (not the headline)")
     args = ap.parse_args()
 
     from pyclaw_amd import parallel, _lib
@@ -116,7 +118,7 @@ def main():
 
     dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
     nxg, nyg = args.nx * dims[0], args.ny * dims[1]
-    claw = build(nxg, nyg, args.math)
+    claw = build(nxg, nyg, args.math, args.unsplit)
     solver, solution = claw.solver, claw.solution
     solver.setup(solution)
     solver.dt = solver.dt_initial
@@ -166,8 +168,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "apps/euler 2D shock-bubble, %dx%d cells per GPU, classic dim-split, "
-                                   "mthlim=[4,4,4,4,2], order 2, source off" % (args.nx, args.ny),
+            "config": {"workload": "apps/euler 2D shock-bubble, %dx%d cells per GPU, classic %s, "
+                                   "mthlim=[4,4,4,4,2], order 2, source off"
+                                   % (args.nx, args.ny, "UNSPLIT order_trans=2" if args.unsplit else "dim-split"),
                        "global_grid": [nxg, nyg], "proc_grid": dims, "math": ("exact (no FMA, IEEE div/sqrt; bit-identical to the reference)" if args.math == "exact"
                                 else "fast (FMA contraction, reciprocal-multiply division; rtol 1e-12 vs reference)"),
                        "launches": {names[0]: int(nl[0]), names[1]: int(nl[1])},

@@ -517,6 +517,113 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     cfl_publish(a.cfl, cflmax);
 }
 
+// ---- unsplit algorithm without scratch planes (no capacity function) ---------------------------------
+// A workgroup of U_WAVES wavefronts takes U_WAVES consecutive slices (x phase: rows of one 64-cell
+// strip; y phase: columns of one 64-row strip).  Every wavefront computes its slice's pieces with the
+// TRANS core, publishes dt/d*gadd(.,1,.) and dt/d*gadd(.,2,.) in LDS, and after one barrier each of
+// the U_WAVES-2 inner slices adds its neighbours' transverse contributions in the reference's order
+// (step2.f:130-137 / :214-218).  Tiles overlap by two slices (U_WAVES/(U_WAVES-2) recompute) instead
+// of moving 8 scratch planes through HBM.
+
+template <class RP, bool FWAVE, int U_WAVES>
+__global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, int nstrips) {
+    constexpr int MEQN = RP::MEQN;
+    constexpr int U_OUT = U_WAVES - 2;
+    __shared__ double gm[U_WAVES][MEQN][WAVE], gp[U_WAVES][MEQN][WAVE];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = threadIdx.x / WAVE;
+    const int ta = blockIdx.x % nstrips, tr = blockIdx.x / nstrips;
+    const int a0 = a.mbc - HALO + ta * STRIP;
+    const int row = a.mbc - 1 + tr * U_OUT + w;        // slices j = 0 .. my+1  <->  rows mbc-1 .. mbc+my
+    const bool slice_ok = row <= a.mbc + a.my;           // wave-uniform
+    const int ca = a0 + lane;
+    const int cc = ca < a.I ? ca : a.I - 1;
+    const int rc = row < a.J ? row : a.J - 1;
+    const long g = (long)rc * a.pitch + cc;
+    double q[MEQN], qadd[MEQN], df[MEQN], g1[MEQN], g2[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + g];
+    double cflmax = 0.0;
+    const bool cfl_ok = slice_ok && (ca >= a.mbc) && (ca <= a.mbc + a.mx) && lane >= 1;
+    lane_core<RP, 1, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2);
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) {
+        gm[w][m][lane] = a.dtd_t * g1[m];
+        gp[w][m][lane] = a.dtd_t * g2[m];
+    }
+    __syncthreads();
+    const bool out_row = w >= 1 && w <= U_OUT && row >= a.mbc && row < a.mbc + a.my;
+    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.mx) && lane >= HALO && lane < WAVE - HALO;
+    if (out_row && owned) {
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {
+            double v = q[m] + gp[w - 1][m][lane];                                   // from slice j-1
+            v = v + qadd[m] - a.dtd * df[m] - a.dtd_t * (g2[m] - g1[m]);           // slice j
+            v = v - gm[w + 1][m][lane];                                            // from slice j+1
+            a.qout[m * a.plane + g] = v;
+        }
+    }
+    cfl_publish(a.cfl, cflmax);
+}
+
+// y phase: qx = result of the x phase (read and overwritten cell by cell), a.qin = qold
+template <class RP, bool FWAVE, int U_WAVES>
+__global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, int ntiles_i, const double *qx) {
+    constexpr int MEQN = RP::MEQN;
+    constexpr int U_OUT = U_WAVES - 2;
+    constexpr int TP = U_WAVES + 1;
+    __shared__ double tile[MEQN][WAVE][TP];
+    __shared__ double gm[U_WAVES][MEQN][WAVE], gp[U_WAVES][MEQN][WAVE];
+    const int ti = blockIdx.x % ntiles_i, tj = blockIdx.x / ntiles_i;
+    const int i0 = a.mbc - 1 + ti * U_OUT;               // slices i = 0 .. mx+1  <->  columns mbc-1 .. mbc+mx
+    const int j0 = a.mbc - HALO + tj * STRIP;
+    {   // cooperative load of qold: 16 lanes per row segment
+        const int c = threadIdx.x % U_WAVES, r = threadIdx.x / U_WAVES;
+        int gi = i0 + c, gj = j0 + r;
+        gi = gi < a.I ? gi : a.I - 1;
+        gj = gj < a.J ? gj : a.J - 1;
+        const long g = (long)gj * a.pitch + gi;
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) tile[m][r][c] = a.qin[m * a.plane + g];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = threadIdx.x / WAVE;
+    const int col = i0 + w;
+    const bool slice_ok = col <= a.mbc + a.mx;
+    const int cj = j0 + lane;
+    double q[MEQN], qadd[MEQN], df[MEQN], g1[MEQN], g2[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) q[m] = tile[m][lane][w];
+    double cflmax = 0.0;
+    const bool cfl_ok = slice_ok && (cj >= a.mbc) && (cj <= a.mbc + a.my) && lane >= 1;
+    lane_core<RP, 2, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2);
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) {
+        gm[w][m][lane] = a.dtd_t * g1[m];
+        gp[w][m][lane] = a.dtd_t * g2[m];
+        tile[m][lane][w] = qadd[m] - a.dtd * df[m] - a.dtd_t * (g2[m] - g1[m]);  // only this wave reads column w
+    }
+    __syncthreads();
+    {   // cooperative combine + store: q6 = ((q3 + gp'(i-1)) + mid(i)) - gm'(i+1)
+        const int c = threadIdx.x % U_WAVES, r = threadIdx.x / U_WAVES;
+        const int gi = i0 + c, gj = j0 + r;
+        const bool ok = c >= 1 && c <= U_OUT && gi >= a.mbc && gi < a.mbc + a.mx && r >= HALO && r < WAVE - HALO &&
+                        gj >= a.mbc && gj < a.mbc + a.my;
+        if (ok) {
+            const long g = (long)gj * a.pitch + gi;
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                double v = qx[m * a.plane + g] + gp[c - 1][m][r];
+                v = v + tile[m][r][c];
+                v = v - gm[c + 1][m][r];
+                a.qout[m * a.plane + g] = v;
+            }
+        }
+    }
+    cfl_publish(a.cfl, cflmax);
+}
+
 // ---- unsplit algorithm: sum the slice pieces into qnew in the reference's order ----------------
 // step2.f runs the x slices j = 0..my+1 in ascending order, each adding into rows j-1, j, j+1,
 // then the y slices i = 0..mx+1 adding into columns i-1, i, i+1.  For interior cell (i,j) that is

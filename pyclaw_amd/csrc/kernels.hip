@@ -78,6 +78,43 @@ int launch_slices(const SweepLaunch &l, std::string &err) {
     return PCL_EINVAL;
 }
 
+// unsplit, no capacity function: both phases without scratch planes (classic.hpp: unsplit_x/y_kernel)
+namespace {
+template <class RP, int UX, int UY> int launch_unsplit_u(const SweepLaunch &l, const double *qx, std::string &err) {
+    const SweepArgs &a = l.a;
+    if (l.ids == 1) {
+        const int nstrips = (a.mx + STRIP - 1) / STRIP;
+        const int ntr = (a.my + (UX - 2) - 1) / (UX - 2);
+        hipLaunchKernelGGL((unsplit_x_kernel<RP, false, UX>), dim3((unsigned)nstrips * ntr), dim3(UX * WAVE), 0,
+                           l.stream, a, nstrips);
+    } else {
+        const int nti = (a.mx + (UY - 2) - 1) / (UY - 2);
+        const int ntj = (a.my + STRIP - 1) / STRIP;
+        hipLaunchKernelGGL((unsplit_y_kernel<RP, false, UY>), dim3((unsigned)nti * ntj), dim3(UY * WAVE), 0,
+                           l.stream, a, nti, qx);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "unsplit launch", e);
+}
+template <class RP> int launch_unsplit_t(const SweepLaunch &l, const double *qx, std::string &err) {
+    static const int var = [] { const char *e = getenv("PCL_TUNE_UNSPLIT"); return e ? atoi(e) : 0; }();
+    switch (var) {   // slices per workgroup in the x / y phase (tools/kbench.py A/B)
+    case 1: return launch_unsplit_u<RP, 8, 8>(l, qx, err);
+    case 2: return launch_unsplit_u<RP, 16, 8>(l, qx, err);
+    case 3: return launch_unsplit_u<RP, 8, 16>(l, qx, err);
+    default: return launch_unsplit_u<RP, 16, 16>(l, qx, err);
+    }
+}
+}  // namespace
+
+int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
+    if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
+    if (l.rp == PCL_RP_ACOUSTICS_2D) return launch_unsplit_t<Acoustics2D>(l, qx, err);
+    if (l.rp == PCL_RP_EULER5_2D) return launch_unsplit_t<Euler5>(l, qx, err);
+    err = "Riemann solver id is not a 2-D solver";
+    return PCL_EINVAL;
+}
+
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err) {
     const dim3 grid((unsigned)((c.I + 255) / 256), (unsigned)c.J);
     if (c.mcapa > 0)

@@ -239,8 +239,45 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt)
     return rc;
 }
 
-// unsplit step (step2.f): x slices and y slices of qold into scratch planes, then one combine pass
+// copy the ghost frame (every cell outside the interior) of an nm-plane array
+__global__ void copy_frame_kernel(const double *src, double *dst, int nm, int I, int J, int mbc, long pitch,
+                                  long plane) {
+    const long ncell = (long)I * J;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell; t += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(t % I), j = (int)(t / I);
+        if (i >= mbc && i < I - mbc && j >= mbc && j < J - mbc) continue;
+        const long g = (long)j * pitch + i;
+        for (int m = 0; m < nm; m++) dst[m * plane + g] = src[m * plane + g];
+    }
+}
+
+// unsplit step (step2.f) without a capacity function: x phase q -> t1, y phase updates t1 in place;
+// transverse contributions travel through LDS inside the kernels (classic.hpp), no scratch planes
+int do_unsplit_lds(pcl_solver *s, double dt) {
+    hipLaunchKernelGGL(copy_frame_kernel, dim3(256), dim3(256), 0, s->stream, s->q, s->t1, s->cfg.meqn, s->I, s->J,
+                       s->cfg.mbc, s->pitch, s->plane);
+    HIP_TRY(hipGetLastError());
+    std::string err;
+    for (int ids = 1; ids <= 2; ids++) {
+        SweepLaunch l;
+        l.a = make_args(s, s->q, s->t1, ids, dt);
+        l.a.trans = s->cfg.method[2];
+        l.a.dtd_t = dt / s->cfg.d[2 - ids];
+        l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = s->stream;
+        pcl_solver::Timed t{};
+        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; hipEventRecord(t.a, s->stream); }
+        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit(l, s->t1, err)
+                                              : pcl::exact::launch_unsplit(l, s->t1, err);
+        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
+        if (rc) return fail(rc, err);
+    }
+    return PCL_OK;
+}
+
+// unsplit step (step2.f), capacity-function form: x slices and y slices of qold into scratch planes,
+// then one combine pass
 int do_unsplit(pcl_solver *s, double dt) {
+    if (s->cfg.method[5] == 0) return do_unsplit_lds(s, dt);
     const size_t qbytes = ((size_t)s->total + 16) * sizeof(double);
     for (int k = 0; k < 9; k++) {
         if (s->scr[k]) continue;

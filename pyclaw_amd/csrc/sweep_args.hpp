@@ -74,6 +74,7 @@ namespace exact {
 int launch_sweep(const SweepLaunch &l, std::string &err);
 int launch_slices(const SweepLaunch &l, std::string &err);   // unsplit: per-slice pieces -> scratch
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
+int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase
 int launch_sharp(const SweepLaunch &l, std::string &err);     // SharpClaw dq of one direction
 int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 }
@@ -81,6 +82,7 @@ namespace fast {
 int launch_sweep(const SweepLaunch &l, std::string &err);
 int launch_slices(const SweepLaunch &l, std::string &err);
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
+int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase
 int launch_sharp(const SweepLaunch &l, std::string &err);
 int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 }
