@@ -160,6 +160,12 @@ int pcl_bc_aux(pcl_solver *s, int idim, int side, int bctype);
  * Python that only touch the strip (user_bc_lower/upper, solver.py:404-405,439-440). */
 int pcl_get_strip(pcl_solver *s, int idim, int side, int width, double *host);
 int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *host);
+/* Gauges (Solver.write_gauge_values, solver.py:731-741: q[:,x,y] and aux[:,x,y] of a few cells
+ * after every step): gather `ncell` interior cells (0-based interior indices ij[2*c], ij[2*c+1];
+ * the second is ignored in 1-D) of the resident q -- and of aux when `aux` is not NULL -- into
+ * q[ncell][meqn] / aux[ncell][maux].  One small kernel + one D2H of ncell*(meqn+maux) doubles
+ * instead of reading the whole state back every step. */
+int pcl_get_cells(pcl_solver *s, int ncell, const int *ij, double *q, double *aux);
 
 /* One homogeneous step of length dt on the resident state (ghost cells must be filled):
  * dim-split  = step2ds(ids=1) then step2ds(ids=2)          clawpack.py:538-546

@@ -1,8 +1,8 @@
 r"""
-Minimal run loop (reference: src/pyclaw/controller.py:195-303).  Only what the solver
-path needs to be driven like the reference's scripts do: output-time grid, ``keep_copy``
-frames, ``solver.setup`` / ``evolve_to_time`` / ``teardown``.  File output, plotting and
-restart (controller.py:77-130,307-433; src/pyclaw/io) are out of scope.
+Run loop (reference: src/pyclaw/controller.py:195-303): output-time grid, ``keep_copy`` frames,
+frame files in the Clawpack ASCII format (``output_format='ascii'``), output functionals
+(``compute_F``/``write_F``, controller.py:307-317), ``solver.setup`` / ``evolve_to_time`` /
+``teardown``.  Plotting and the hdf5/netcdf/petsc formats are out of scope.
 """
 import copy
 import logging
@@ -22,8 +22,16 @@ class Controller(object):
         self.out_times = np.linspace(0.0, 1.0, self.nout + 1)
         self.nstepout = 1
         self.tfinal = 1.0
-        self.output_format = None
+        self.output_format = None       # 'ascii' writes fort.qNNNN / fort.tNNNN into outdir
         self.outdir = './_output'
+        self.output_file_prefix = None
+        self.output_options = {}
+        self.write_aux_init = False
+        self.write_aux_always = False
+        self.compute_p = None
+        self.compute_F = None
+        self.F_file_name = 'F'
+        self.start_frame = 0
         self.t0 = None
         self.logger = logging.getLogger('controller')
 
@@ -38,8 +46,7 @@ class Controller(object):
             raise Exception("Initial solution is not valid.")
 
     def run(self):
-        r"""controller.py:195-303 (outstyle 1, 2 and 3; no file output)."""
-        frame = 0
+        r"""controller.py:195-303 (outstyle 1, 2 and 3)."""
         self.solver.setup(self.solution)
         self.solver.dt = self.solver.dt_initial
         self.check_validity()
@@ -55,6 +62,16 @@ class Controller(object):
 
         if self.keep_copy:
             self.frames.append(copy.deepcopy(self.solution))
+        frame = self.start_frame
+        if self.output_format is not None:
+            if self.compute_p is not None:
+                self.compute_p(self.solution.state)
+                self.solution.write(frame, self.outdir, self.output_format, self.output_file_prefix + '_p'
+                                    if self.output_file_prefix else 'claw_p', write_aux=False, write_p=True)
+            self.solution.write(frame, self.outdir, self.output_format, self.output_file_prefix,
+                                self.write_aux_init, self.output_options)
+        self.write_F('w')
+        self.solver.write_gauge_values(self.solution)    # initial gauge values (controller.py:225-226)
 
         status = None
         for t in output_times[1:]:
@@ -66,5 +83,32 @@ class Controller(object):
             frame += 1
             if self.keep_copy:
                 self.frames.append(copy.deepcopy(self.solution))
+            if self.output_format is not None:
+                if self.compute_p is not None:
+                    self.compute_p(self.solution.state)
+                    self.solution.write(frame, self.outdir, self.output_format, self.output_file_prefix + '_p'
+                                        if self.output_file_prefix else 'claw_p', write_aux=False, write_p=True)
+                self.solution.write(frame, self.outdir, self.output_format, self.output_file_prefix,
+                                    self.write_aux_always, self.output_options)
+            self.write_F()
+            for f in self.solution.state.grid.gauge_files:
+                f.flush()
         self.solver.teardown()
+        for f in self.solution.state.grid.gauge_files:
+            f.close()
         return status
+
+    def write_F(self, mode='a'):
+        """Output functionals sum|F_i| at output times (controller.py:307-317; petclaw sums over ranks)."""
+        if self.compute_F is None:
+            return
+        import os
+        from . import parallel
+        state = self.solution.state
+        self.compute_F(state)
+        sums = [float(np.sum(np.abs(state.F[i, ...]))) for i in range(state.F.shape[0])]
+        sums = parallel.allreduce_sum_host(sums)
+        if parallel.rank() == 0:
+            os.makedirs(self.outdir, exist_ok=True)
+            with open(os.path.join(self.outdir, self.F_file_name + '.txt'), mode) as f:
+                f.write(' '.join([str(self.solution.t)] + [str(v) for v in sums]) + '\n')

@@ -552,6 +552,45 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
     return PCL_OK;
 }
 
+__global__ void gather_cells_kernel(const double *q, const double *aux, const int *ij, double *out, int ncell,
+                                    int nq, int na, int mbc, int ndim, long pitch, long plane) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = nq + na;
+    if (t >= ncell * per) return;
+    const int c = t / per, m = t % per;
+    const long cell = (long)(ndim > 1 ? ij[2 * c + 1] + mbc : 0) * pitch + ij[2 * c] + mbc;
+    out[t] = m < nq ? q[m * plane + cell] : aux[(m - nq) * plane + cell];
+}
+
+int pcl_get_cells(pcl_solver *s, int ncell, const int *ij, double *q, double *aux) {
+    if (!s || !ij || !q) return fail(PCL_EINVAL, "null argument");
+    if (ncell <= 0) return PCL_OK;
+    const int nq = s->cfg.meqn, na = (aux && s->aux) ? s->cfg.maux : 0, per = nq + na;
+    if (aux && s->cfg.maux > 0 && !s->aux) return fail(PCL_EINVAL, "pcl_get_cells: aux requested but never uploaded");
+    for (int c = 0; c < ncell; c++) {
+        const int i = ij[2 * c], j = s->cfg.ndim > 1 ? ij[2 * c + 1] : 0;
+        if (i < 0 || i >= s->cfg.n[0] || j < 0 || j >= (s->cfg.ndim > 1 ? s->cfg.n[1] : 1))
+            return fail(PCL_EINVAL, "pcl_get_cells: cell index outside the interior");
+    }
+    // staging layout: [ncell*per doubles of output][ncell*2 ints of indices]
+    const size_t out_bytes = (size_t)ncell * per * sizeof(double), idx_bytes = (size_t)ncell * 2 * sizeof(int);
+    if (out_bytes + idx_bytes > s->stage_bytes) return fail(PCL_EINVAL, "pcl_get_cells: too many cells for the staging buffer");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    int *dij = reinterpret_cast<int *>(reinterpret_cast<char *>(s->stage) + out_bytes);
+    HIP_TRY(hipMemcpyAsync(dij, ij, idx_bytes, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(gather_cells_kernel, dim3((ncell * per + 255) / 256), dim3(256), 0, s->stream, cur(s),
+                       s->aux, dij, s->stage, ncell, nq, na, s->cfg.mbc, s->cfg.ndim, s->pitch, s->plane);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> tmp((size_t)ncell * per);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), s->stage, out_bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int c = 0; c < ncell; c++) {
+        for (int m = 0; m < nq; m++) q[(size_t)c * nq + m] = tmp[(size_t)c * per + m];
+        for (int m = 0; m < na; m++) aux[(size_t)c * s->cfg.maux + m] = tmp[(size_t)c * per + nq + m];
+    }
+    return PCL_OK;
+}
+
 static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate, bool aux = false) {
     pcl::RpParams cs;  // the constant state travels as a kernel argument: no copy, no sync
     for (int k = 0; k < 8; k++) cs.v[k] = (cstate && k < s->cfg.meqn) ? cstate[k] : 0.0;

@@ -86,6 +86,7 @@ class Grid(object):
         self.gridno = 1
         self.gauges = []
         self.gauge_files = []
+        self.gauge_path = './_output/_gauges/'
         self._dimensions = []
         if isinstance(dimensions, Dimension):
             dimensions = [dimensions]
@@ -98,6 +99,22 @@ class Grid(object):
                             % dimension.name)
         self._dimensions.append(dimension.name)
         setattr(self, dimension.name, dimension)
+
+    def add_gauges(self, gauge_coords):
+        r"""Grid indices + output files of the gauges that lie in this rank's block (grid.py:519-545;
+        file name and the floor(x/d) index rule are the reference's)."""
+        import os
+        from math import floor
+        os.makedirs(self.gauge_path, exist_ok=True)
+        for gauge in gauge_coords:
+            gauge_ind = [int(floor(gauge[n] / self.d[n])) for n in range(self.ndim)]
+            if all(self.nstart[n] <= gauge_ind[n] < self.nend[n] for n in range(self.ndim)):
+                gauge_ind = [gauge_ind[n] - self.nstart[n] for n in range(self.ndim)]
+                gauge_path = self.gauge_path + 'gauge' + '_'.join(str(coord) for coord in gauge) + '.txt'
+                if os.path.isfile(gauge_path):
+                    os.remove(gauge_path)
+                self.gauges.append(list(gauge_ind))
+                self.gauge_files.append(open(gauge_path, 'a'))
 
     def get_dim_attribute(self, attr):
         return [getattr(getattr(self, name), attr) for name in self._dimensions]

@@ -94,6 +94,17 @@ def allreduce_max_host(value):
     return float(t[0])
 
 
+def allreduce_sum_host(values):
+    """Host-side sum all-reduce of a short list (output functionals at output times)."""
+    dist = _state["dist"]
+    if dist is None:
+        return list(values)
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t]
+
+
 def proc_grid(n_global, size):
     """Processor grid for `size` blocks: PETSc DMDA's default rule (DMSetUp_DA_2D).
 

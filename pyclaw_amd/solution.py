@@ -1,6 +1,6 @@
 r"""
 Solution: a list of states + grids with a common time (reference: src/pyclaw/solution.py).
-Frame reading/writing (solution.py:356-448, src/pyclaw/io) is out of scope.
+``write`` / ``read`` dispatch to ``pyclaw_amd.io`` (ASCII frames only; solution.py:356-448).
 """
 from .grid import Grid
 from .state import State
@@ -19,8 +19,12 @@ class Solution(object):
                 self.grids.append(s.grid)
         elif len(arg) == 1 and isinstance(arg[0], Grid):
             raise Exception("A Solution is built from State objects: Solution(State(grid,meqn))")
+        elif len(arg) >= 1 and isinstance(arg[0], int):
+            # Solution(frame, path=..., format='ascii'): read a frame (solution.py:187-209)
+            self.read(arg[0], kargs.get('path', './'), kargs.get('format', 'ascii'),
+                      kargs.get('file_prefix', 'fort'), kargs.get('read_aux', False))
         elif len(arg) > 0:
-            raise Exception("Invalid argument list; frame reading is not part of pyclaw_amd")
+            raise Exception("Invalid argument list")
 
     @property
     def state(self):
@@ -49,6 +53,23 @@ class Solution(object):
 
     def is_valid(self):
         return all(s.is_valid() for s in self.states)
+
+    def write(self, frame, path='./', format='ascii', file_prefix=None, write_aux=False, options={},
+              write_p=False):
+        """solution.py:356-404 (ascii only)"""
+        from . import io
+        formats = format if isinstance(format, (list, tuple)) else [format]
+        for fmt in formats:
+            if fmt != 'ascii':
+                raise NotImplementedError("pyclaw_amd writes the Clawpack ascii format only")
+            io.write_ascii(self, frame, path, file_prefix or 'fort', write_aux, options, write_p)
+
+    def read(self, frame, path='./', format='ascii', file_prefix=None, read_aux=True, options={}):
+        """solution.py:406-448 (ascii only)"""
+        from . import io
+        if format != 'ascii':
+            raise NotImplementedError("pyclaw_amd reads the Clawpack ascii format only")
+        io.read_ascii(self, frame, path, file_prefix or 'fort', read_aux, options)
 
     def __deepcopy__(self, memo={}):
         import copy

@@ -17,6 +17,11 @@ from . import _lib, parallel
 from .cfl import CFL
 
 
+def default_compute_gauge_values(q, aux):
+    r"""By default, record values of q at gauges (solver.py:26-29)."""
+    return q
+
+
 class BC():
     """Boundary condition types (solver.py:17-23)."""
     custom = 0
@@ -455,16 +460,27 @@ class Solver(object):
 
     # ------------------------------------------------------------------ gauges
     def write_gauge_values(self, solution):
-        r"""solver.py:731-741"""
-        gauges = solution.state.grid.gauges
+        r"""solver.py:731-741.  While the state is resident the gauge cells are gathered on the device
+        (pcl_get_cells: ngauges*(meqn+maux) doubles over PCIe) instead of pulling the whole q."""
+        grid = solution.state.grid
+        gauges = grid.gauges
         if not gauges:
             return
-        self._pull(solution.state)
-        for i, gauge in enumerate(gauges):
-            x = gauge[0]
-            y = gauge[1]
-            aux = solution.state.aux[:, x, y]
-            q = solution.state.q[:, x, y]
-            p = self.compute_gauge_values(q, aux)
-            t = solution.t
-            solution.state.grid.gauge_files[i].write(str(t) + ' ' + ' '.join(str(j) for j in p) + '\n')
+        state = solution.state
+        compute = self.compute_gauge_values or default_compute_gauge_values
+        if self._resident and self._h is not None:
+            n = len(gauges)
+            ij = np.zeros((n, 2), dtype=np.int32)
+            for c, g in enumerate(gauges):
+                ij[c, :len(g)] = g
+            qv = np.empty((n, state.meqn))
+            av = np.empty((n, max(state.maux, 1)))
+            _lib.check(_lib.lib().pcl_get_cells(self._h, n, _lib.i(ij), _lib.d(qv),
+                                                _lib.d(av) if state.maux > 0 else None))
+            cells = [(qv[c], av[c, :state.maux]) for c in range(n)]
+        else:
+            cells = [(state.q[(slice(None),) + tuple(g)],
+                      state.aux[(slice(None),) + tuple(g)] if state.aux is not None else None) for g in gauges]
+        for i, (q, aux) in enumerate(cells):
+            p = compute(q, aux)
+            grid.gauge_files[i].write(str(solution.t) + ' ' + ' '.join(str(j) for j in p) + '\n')

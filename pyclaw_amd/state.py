@@ -38,6 +38,26 @@ class State(object):
         return self.q.shape[0]
 
     @property
+    def mp(self):
+        return self.p.shape[0] if self.p is not None else 0
+
+    @mp.setter
+    def mp(self, mp):
+        if self.p is not None:
+            raise Exception('Cannot change state.mp after aux is initialized.')
+        self.p = self.new_array(mp)
+
+    @property
+    def mF(self):
+        return self.F.shape[0] if self.F is not None else 0
+
+    @mF.setter
+    def mF(self, mF):
+        if self.F is not None:
+            raise Exception('Cannot change state.mF after aux is initialized.')
+        self.F = self.new_array(mF)
+
+    @property
     def maux(self):
         return self.aux.shape[0] if self.aux is not None else 0
 

@@ -142,3 +142,31 @@ def test_strang_source_and_start_step(coracle):
     assert claw.solver.status['numsteps'] == st['numsteps'] and p.nrejected >= 1
     assert len(calls) == st['numsteps'] + p.nrejected
     assert np.array_equal(claw.frames[1].state.q, p.q)
+
+
+def test_controller_ascii_frames_and_gauges(tmp_path):
+    """Controller.output_format='ascii' + gauges (controller.py:225-300, solver.py:731-741):
+    frames read back equal the kept copies to the file's 9 digits; the gauge series (device gather,
+    pcl_get_cells) has one line per accepted step and reproduces the frame values at output times bit for bit."""
+    import pyclaw_amd as pyclaw
+    claw = problems.acoustics2D(pyclaw, mx=60, my=50, nout=3, run=False)
+    grid = claw.solution.state.grid
+    grid.gauge_path = str(tmp_path / "_gauges") + os.sep
+    grid.add_gauges([(0.25, 0.5), (0.9, 0.1)])
+    assert grid.gauges == [[7, 12], [27, 2]]            # floor(x/d): the reference's index rule (grid.py:537)
+    claw.output_format = 'ascii'
+    claw.outdir = str(tmp_path)
+    claw.run()
+    for k, kept in enumerate(claw.frames):
+        back = pyclaw.Solution(k, path=str(tmp_path))
+        assert back.t == float("%18.8e" % kept.t)
+        assert np.allclose(back.state.q, kept.state.q, rtol=1e-8, atol=1e-99)
+        assert back.state.grid.n == [60, 50] and back.state.grid.lower == [-1.0, -1.0]
+    for g, name in zip(grid.gauges, ("gauge0.25_0.5.txt", "gauge0.9_0.1.txt")):
+        rows = [[float(v) for v in line.split()] for line in open(os.path.join(grid.gauge_path, name))]
+        times = [r[0] for r in rows]
+        assert times[0] == 0.0 and all(b > a for a, b in zip(times, times[1:]))
+        assert len(rows) == claw.nout * claw.solver.status['numsteps'] + 1     # status counts the last evolve call
+        series = {r[0]: r[1:] for r in rows}
+        for kept in claw.frames:
+            assert series[kept.t] == list(kept.state.q[:, g[0], g[1]])

@@ -1,0 +1,49 @@
+"""
+CPU: Clawpack ASCII frame files.  Format fixture: the reference's own
+test/old_tests/data/advection_test/fort.q0000 (copied to tests/golden/; written by an older writer
+with %16.8e data columns and 'ngrids' in fort.t): read -> write reproduces the header bytes and every
+value; the data column width is the current writer's %18.8e (src/pyclaw/io/ascii.py:136).
+"""
+import os
+
+import numpy as np
+
+import pyclaw_amd as pyclaw
+from pyclaw_amd import io
+
+
+def test_roundtrip_reference_frame_bytes(tmp_path, golden_dir):
+    src = tmp_path / "in"
+    src.mkdir()
+    for ext in ("q", "t"):
+        data = open(os.path.join(golden_dir, "advection_fort.%s0000" % ext)).read()
+        (src / ("fort.%s0000" % ext)).write_text(data)
+    sol = pyclaw.Solution()
+    io.read_ascii(sol, 0, str(src))
+    assert sol.state.q.shape == (1, 100) and sol.t == 1.0 and sol.state.grid.x.d == 0.01
+    out = tmp_path / "out"
+    sol.write(0, str(out))
+    new, old = (out / "fort.q0000").read_text().splitlines(), (src / "fort.q0000").read_text().splitlines()
+    assert new[:6] == old[:6] and len(new) == len(old) == 106
+    assert [l.strip() for l in new[6:]] == [l.strip() for l in old[6:]]
+    assert all(len(l) == 18 for l in new[6:])
+    # fort.t: the reference's current writer says 'nstates' where this old file says 'ngrids'
+    t_lines = (out / "fort.t0000").read_text().splitlines()
+    assert t_lines[0] == "    1.00000000e+00     time" and t_lines[2].split() == ["1", "nstates"]
+
+
+def test_2d_write_read(tmp_path):
+    g = pyclaw.Grid([pyclaw.Dimension('x', 0., 1., 4), pyclaw.Dimension('y', -1., 1., 3)])
+    st = pyclaw.State(g, 2, 1)
+    st.q[...] = np.arange(24).reshape(2, 4, 3) * 0.125
+    st.aux[...] = 7.0
+    st.t = 0.5
+    sol = pyclaw.Solution(st)
+    sol.write(3, str(tmp_path), write_aux=True)
+    lines = (tmp_path / "fort.q0003").read_text().splitlines()
+    assert lines[2].split() == ["4", "mx"] and lines[3].split() == ["3", "my"]
+    assert lines[9] == "%18.8e%18.8e" % (st.q[0, 0, 0], st.q[1, 0, 0])       # x fastest, one cell per line
+    assert lines[13] == ""                                                  # blank line after each row
+    back = pyclaw.Solution(3, path=str(tmp_path), read_aux=True)
+    assert np.array_equal(back.state.q, st.q) and back.t == 0.5
+    assert np.array_equal(back.state.aux, st.aux)
