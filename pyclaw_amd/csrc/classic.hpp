@@ -323,8 +323,32 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     // any moment stream whole rows.  (With the across index fastest in the x pass, all resident
     // workgroups read the same 2 KB column band of ~1000 rows whose pitch is 32 KB + 128 B: the
     // requests pile up on a few HBM channels and the pass drops to ~3.9 TB/s even as a pure copy.)
-    const int tb = IXY == 1 ? blockIdx.x / ntiles_along : blockIdx.x % ntiles_across;
-    const int ta = IXY == 1 ? blockIdx.x % ntiles_along : blockIdx.x / ntiles_across;
+    int tb = IXY == 1 ? blockIdx.x / ntiles_along : blockIdx.x % ntiles_across;
+    int ta = IXY == 1 ? blockIdx.x % ntiles_along : blockIdx.x / ntiles_across;
+    if (IXY == 1 && !DIM1 && !TRANS && a.sub != 0) {  // workgroup-uniform: interior box / its complement
+        int idx = blockIdx.x;
+        const int bw = a.box[3] - a.box[2];
+        if (a.sub == 1) {
+            tb = a.box[0] + idx / bw;
+            ta = a.box[2] + idx % bw;
+        } else {
+            const int top = a.box[0] * ntiles_along, bot = (ntiles_across - a.box[1]) * ntiles_along;
+            if (idx < top) {
+                tb = idx / ntiles_along;
+                ta = idx % ntiles_along;
+            } else if (idx < top + bot) {
+                idx -= top;
+                tb = a.box[1] + idx / ntiles_along;
+                ta = idx % ntiles_along;
+            } else {
+                idx -= top + bot;
+                const int side = ntiles_along - bw;
+                const int k = idx % side;
+                tb = a.box[0] + idx / side;
+                ta = k < a.box[2] ? k : a.box[3] + (k - a.box[2]);
+            }
+        }
+    }
     // y pass: column tiles start LEAD cells before cell 0 so that they sit on 128-byte lines
     const int b0 = IXY == 1 ? tb * T::ACROSS : tb * T::ACROSS - (LINE - a.mbc);
     const int a0 = a.mbc - HALO + ta * (T::NSTRIP * STRIP);

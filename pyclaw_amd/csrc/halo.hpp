@@ -130,9 +130,11 @@ public:
     }
 
     // exchange the ghost frame of an nm-component SoA array
-    int exchange(double *q, int nm, long pitch, long plane, std::string &err) {
+    // `on`: stream to enqueue on (default: the solver stream given to init)
+    int exchange(double *q, int nm, long pitch, long plane, std::string &err, hipStream_t on = nullptr) {
         if (!active) { err = "halo exchange before pcl_comm_init"; return -1; }
         Api &a = api();
+        hipStream_t stream_ = on ? on : this->stream_;
         dim3 grid(64, 8);
         hipLaunchKernelGGL(halo_pack, grid, dim3(256), 0, stream_, q, send_, plan_, nm, pitch, plane, false);
         ncclResult_t r = a.ncclGroupStart();

@@ -5,6 +5,7 @@
 //                                                   division; checked at rtol 1e-12
 // Distinct namespaces keep the two sets of template instantiations apart at link time.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 
@@ -29,7 +30,18 @@ template <class RP, int IXY, bool DIM1, bool TRANS = false> int launch(const Swe
     const int m_along = IXY == 1 ? a.mx : a.my;
     const int ntiles_across = (n_across + T::ACROSS - 1) / T::ACROSS;
     const int ntiles_along = (m_along + T::NSTRIP * STRIP - 1) / (T::NSTRIP * STRIP);
-    const dim3 grid((unsigned)ntiles_across * (unsigned)ntiles_along);
+    unsigned nblocks = (unsigned)ntiles_across * (unsigned)ntiles_along;
+    if (a.sub != 0) {
+        if (IXY != 1 || DIM1 || TRANS || a.box[0] < 0 || a.box[1] > ntiles_across || a.box[2] < 0 ||
+            a.box[3] > ntiles_along || a.box[0] >= a.box[1] || a.box[2] >= a.box[3]) {
+            err = "tile subset: bad box";
+            return PCL_EINVAL;
+        }
+        const unsigned inside = (unsigned)(a.box[1] - a.box[0]) * (unsigned)(a.box[3] - a.box[2]);
+        nblocks = a.sub == 1 ? inside : nblocks - inside;
+        if (nblocks == 0) return PCL_OK;
+    }
+    const dim3 grid(nblocks);
     if (a.mcapa > 0)
         hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, false, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
                            ntiles_across, ntiles_along);
@@ -62,6 +74,21 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
     err = "Riemann solver id is not a 2-D solver";
     return PCL_EINVAL;
 }
+
+#if !PCL_FAST
+bool x_interior_box(const SweepArgs &a, int box[4]) {
+    using T = TileShape<1>;
+    constexpr int ADV = T::NSTRIP * STRIP;  // cells a tile advances along the row
+    const int ntb = (a.J + T::ACROSS - 1) / T::ACROSS, nta = (a.mx + ADV - 1) / ADV;
+    // rows b0 = ACROSS*tb .. b0+ACROSS-1 inside [mbc, J-mbc); cells a0 = mbc-HALO+ADV*ta .. a0+ALONG-1 inside [mbc, I-mbc)
+    box[0] = (a.mbc + T::ACROSS - 1) / T::ACROSS;
+    box[1] = std::min(ntb, (a.J - a.mbc) / T::ACROSS);
+    box[2] = (HALO + ADV - 1) / ADV;
+    const int room = a.I - a.mbc - T::ALONG - (a.mbc - HALO);  // ADV*ta <= room
+    box[3] = room < 0 ? 0 : std::min(nta, room / ADV + 1);
+    return box[0] < box[1] && box[2] < box[3];
+}
+#endif
 
 // unsplit (step2.f): per-slice pieces of one direction into the scratch planes
 int launch_slices(const SweepLaunch &l, std::string &err) {

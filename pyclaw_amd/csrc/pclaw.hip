@@ -53,12 +53,16 @@ struct pcl_solver {
     int vbc_on = 0;       // next x pass evaluates these BCs while loading (pcl_bc_step)
     int vbc[4] = {-1, -1, -1, -1};
     double vconst[4][8] = {};
-    struct Timed { hipEvent_t a, b; int which; };
+    struct Timed { hipEvent_t a, b; int which; bool count; };
     std::vector<Timed> timed;
     std::vector<hipEvent_t> evpool;
     double kt_ms[2] = {0, 0};
     long kt_n[2] = {0, 0};
     pcl::Halo halo;
+    // halo exchange overlapped with the interior of the x pass (pcl_bc_step, dim-split 2-D)
+    hipStream_t hstream = nullptr;
+    hipEvent_t ev_h0 = nullptr, ev_h1 = nullptr;
+    int overlap = 1;
 };
 
 static inline double *&cur(pcl_solver *s) { return s->sel == 0 ? s->q : s->sreg[s->sel]; }
@@ -203,7 +207,7 @@ int drain_timing(pcl_solver *s) {
         float ms = 0;
         hipEventElapsedTime(&ms, t.a, t.b);
         s->kt_ms[t.which] += ms;
-        s->kt_n[t.which] += 1;
+        s->kt_n[t.which] += t.count ? 1 : 0;
         s->evpool.push_back(t.a);
         s->evpool.push_back(t.b);
     }
@@ -212,14 +216,22 @@ int drain_timing(pcl_solver *s) {
 }
 
 // one directional sweep qin -> qout; ids 1 = x (or the 1-D step), 2 = y
-int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt) {
-    const SweepArgs a = make_args(s, qin, qout, ids, dt);
+// sub/box: tile subset of the x pass (sweep_args.hpp); the second launch of a split pass adds its time to
+// the pass without counting as another launch
+int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt, int sub = 0,
+             const int *box = nullptr, hipStream_t on = nullptr) {
+    hipStream_t stream = on ? on : s->stream;
+    SweepArgs a = make_args(s, qin, qout, ids, dt);
+    a.sub = sub;
+    if (sub) for (int k = 0; k < 4; k++) a.box[k] = box[k];
     pcl_solver::Timed t{};
-    if (s->timing) {
+    const bool timed = s->timing && !on;  // a launch on the halo stream runs beside the interior: not timed
+    if (timed) {
         t.a = get_event(s);
         t.b = get_event(s);
         t.which = ids - 1;
-        hipEventRecord(t.a, s->stream);
+        t.count = sub != 2;
+        hipEventRecord(t.a, stream);
     }
     SweepLaunch l;
     l.a = a;
@@ -227,12 +239,12 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt)
     l.rp = s->cfg.rp;
     l.ids = ids;
     l.fwave = s->cfg.fwave;
-    l.stream = s->stream;
+    l.stream = stream;
     std::string err;
     int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sweep(l, err) : pcl::exact::launch_sweep(l, err);
     if (rc) fail(rc, err);
-    if (s->timing) {
-        hipEventRecord(t.b, s->stream);
+    if (timed) {
+        hipEventRecord(t.b, stream);
         s->timed.push_back(t);
         if (s->timed.size() >= 2048) drain_timing(s);
     }
@@ -443,7 +455,11 @@ void pcl_destroy(pcl_solver *s) {
     if (!s) return;
     hipSetDevice(s->cfg.device);
     if (s->stream) hipStreamSynchronize(s->stream);
+    if (s->hstream) hipStreamSynchronize(s->hstream);
     s->halo.destroy();
+    if (s->ev_h0) hipEventDestroy(s->ev_h0);
+    if (s->ev_h1) hipEventDestroy(s->ev_h1);
+    if (s->hstream) hipStreamDestroy(s->hstream);
     for (auto &t : s->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto &e : s->evpool) hipEventDestroy(e);
     for (double *p : {s->q, s->t1, s->t2, s->bak, s->aux, s->stage})
@@ -667,10 +683,6 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     if (!s || !bc || !cfl) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    if (s->halo.active) {
-        std::string err;
-        if (s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);
-    }
     for (int k = 0; k < 2 * s->cfg.ndim; k++) {
         const int t = bc[k];
         if (t >= 0 && t != PCL_BC_CUSTOM && t != PCL_BC_OUTFLOW && t != PCL_BC_PERIODIC && t != PCL_BC_REFLECTING)
@@ -680,6 +692,52 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     // Dimension-split steps (and 1-D): the first pass evaluates the boundary conditions while it
     // loads its tiles -- no ghost-fill launches (each costs ~5 us of launch latency per step).
     const bool fused = s->cfg.meqn <= 8 && (s->cfg.ndim == 1 || s->cfg.method[2] < 0);
+    // Decomposed dim-split 2-D step: the halo exchange runs on its own stream while the x pass does the
+    // tiles that read no ghost cell; the rim tiles follow once the ghost frame has arrived.
+    int box[4];
+    const bool overlapped = s->halo.active && fused && s->cfg.ndim == 2 && s->overlap && s->sel == 0 &&
+                            pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, dt), box);
+    if (s->halo.active && !overlapped) {
+        std::string err;
+        if (s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);
+    }
+    if (overlapped) {
+        for (int k = 0; k < 4; k++) {
+            s->vbc[k] = bc[k];
+            for (int m = 0; m < 8; m++)
+                s->vconst[k][m] = (s->vbc[k] == PCL_BC_CUSTOM) ? cstate[k * PCL_MAX_RP_PARAMS + m] : 0.0;
+        }
+        std::string err;
+        int rc;
+        s->vbc_on = 1;
+        if (s->overlap == 2) {
+            // test mode (PCL_HALO_OVERLAP=2): same launches on ONE stream with the interior tiles strictly
+            // BEFORE the exchange -- an interior tile that read a ghost cell would see the stale frame
+            rc = do_sweep(s, s->q, s->t1, 1, dt, 1, box);
+            if (!rc && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err)) rc = fail(PCL_ECOMM, err);
+        } else {
+            HIP_TRY(hipEventRecord(s->ev_h0, s->stream));          // q of the previous step is complete
+            HIP_TRY(hipStreamWaitEvent(s->hstream, s->ev_h0, 0));
+            if (s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, s->hstream)) {
+                s->vbc_on = 0;
+                return fail(PCL_ECOMM, err);
+            }
+            rc = do_sweep(s, s->q, s->t1, 1, dt, 1, box);      // interior tiles, concurrent with the exchange
+            // rim tiles (ghost frame + physical BCs) behind the exchange on ITS stream: they start as soon as
+            // the frame has arrived and fill the machine next to the interior kernel's tail
+            if (!rc) rc = do_sweep(s, s->q, s->t1, 1, dt, 2, box, s->hstream);
+            hipError_t he = hipEventRecord(s->ev_h1, s->hstream);
+            if (he == hipSuccess) he = hipStreamWaitEvent(s->stream, s->ev_h1, 0);
+            if (!rc && he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream join: ") + hipGetErrorString(he));
+        }
+        if (!rc && s->overlap == 2) rc = do_sweep(s, s->q, s->t1, 1, dt, 2, box);
+        s->vbc_on = 0;
+        if (rc) return bail(s, rc);
+        if (int rc2 = do_sweep(s, s->t1, s->t2, 2, dt)) return bail(s, rc2);
+        std::swap(s->q, s->t2);
+        s->undo_slot = &s->t2;
+        return read_cfl(s, cfl);
+    }
     if (fused) {
         for (int k = 0; k < 4; k++) {
             s->vbc[k] = k < 2 * s->cfg.ndim ? bc[k] : -1;
@@ -941,6 +999,13 @@ int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], cons
     const int nmax = s->cfg.meqn > s->cfg.maux ? s->cfg.meqn : s->cfg.maux;
     if (s->halo.init(nranks, rank, uid, neighbors, s->I, s->J, s->cfg.mbc, nmax, s->stream, err))
         return fail(PCL_ECOMM, err);
+    if (!s->hstream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_h0, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
+    }
+    const char *e = getenv("PCL_HALO_OVERLAP");
+    s->overlap = e ? atoi(e) : 1;
     return PCL_OK;
 }
 

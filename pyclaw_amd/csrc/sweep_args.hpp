@@ -34,6 +34,11 @@ struct SweepArgs {
     int vbc_on;
     int vbc[4];
     double vconst[4][8];
+    // Tile subset of the x pass, for overlapping the halo exchange with the interior (pclaw.hip,
+    // step_split_overlapped): 0 = every tile, 1 = only tiles inside box = [tb_lo,tb_hi) x [ta_lo,ta_hi)
+    // (they read no ghost cell), 2 = only the tiles outside the box.
+    int sub;
+    int box[4];
     // unsplit algorithm (step2.f) only:
     int trans;        // method(3): 0 no transverse terms, 1 increment waves, 2 + correction waves
     double dtd_t;     // dt/d of the transverse direction
@@ -72,6 +77,8 @@ struct SweepLaunch {
 // defined in kernels.hip, once per arithmetic mode; returns 0 or a PCL_E* code + message
 namespace exact {
 int launch_sweep(const SweepLaunch &l, std::string &err);
+// x-pass tiles [tb_lo,tb_hi) x [ta_lo,ta_hi) that read no ghost cell; false if there are none
+bool x_interior_box(const SweepArgs &a, int box[4]);
 int launch_slices(const SweepLaunch &l, std::string &err);   // unsplit: per-slice pieces -> scratch
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase

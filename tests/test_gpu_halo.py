@@ -118,3 +118,52 @@ def test_step_with_comm_single_rank():
         finally:
             lib.pcl_destroy(h)
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and res[0][1] > 0
+
+
+@pytest.mark.parametrize("mx,my,overlap", [(1000, 37, 1), (482, 64, 1), (723, 9, 1), (100, 30, 1), (1000, 37, 0), (1000, 37, 2),
+                                               (481, 10, 2), (962, 11, 2)])
+def test_overlapped_step_equals_periodic(mx, my, overlap, monkeypatch):
+    """pcl_bc_step on a block whose 8 neighbours are itself (halo exchange on its own stream, overlapped
+    with the interior tiles of the x pass; rim tiles afterwards) == the same steps with local periodic
+    BCs, bit for bit, Courant number included.  (100, 30) has no interior box -> sequential fallback;
+    overlap=0 forces the sequential path; overlap=2 is the deterministic race check: interior tiles are
+    launched strictly BEFORE the exchange, so any ghost cell they read would be stale (NaN-poisoned here)."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    monkeypatch.setenv("PCL_HALO_OVERLAP", str(overlap))
+    g = 2
+    rng = np.random.default_rng(11)
+    q0 = np.empty((5, mx, my), order="F")
+    q0[0] = 1 + 0.3 * rng.random((mx, my))
+    q0[1] = 0.3 * rng.standard_normal((mx, my))
+    q0[2] = 0.2 * rng.standard_normal((mx, my))
+    q0[3] = 2.5 + 0.5 * rng.random((mx, my))
+    q0[4] = rng.random((mx, my))
+    res = []
+    for with_comm in (False, True):
+        h = make_solver(L, mx, my)
+        try:
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
+                bc = np.full(4, -1, dtype=np.int32)
+            else:
+                bc = np.full(4, 2, dtype=np.int32)
+            poison = np.full((5, mx + 2 * g, my + 2 * g), np.nan, order="F")   # ghost frame starts as NaN
+            L.check(lib.pcl_put_q(h, L.d(poison), 1))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            consts = np.zeros(4 * 8)
+            cfls = []
+            for _ in range(3):
+                cfl = C.c_double()
+                L.check(lib.pcl_bc_step(h, L.i(bc), L.d(consts), 2e-4 * 100 / mx, C.cast(C.byref(cfl), L.dp)))
+                cfls.append(cfl.value)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            res.append((out, cfls))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and 0 < res[0][1][0] < 1
+    assert np.array_equal(res[0][0], res[1][0])
+    assert not np.array_equal(res[0][0], q0)
