@@ -1,6 +1,6 @@
 r"""
 Solution: a list of states + grids with a common time (reference: src/pyclaw/solution.py).
-``write`` / ``read`` dispatch to ``pyclaw_amd.io`` (ASCII frames only; solution.py:356-448).
+``write`` / ``read`` dispatch to ``pyclaw_amd.io`` ('ascii' frames, 'block' checkpoints; solution.py:356-448).
 """
 from .grid import Grid
 from .state import State
@@ -22,7 +22,7 @@ class Solution(object):
         elif len(arg) >= 1 and isinstance(arg[0], int):
             # Solution(frame, path=..., format='ascii'): read a frame (solution.py:187-209)
             self.read(arg[0], kargs.get('path', './'), kargs.get('format', 'ascii'),
-                      kargs.get('file_prefix', 'fort'), kargs.get('read_aux', False))
+                      kargs.get('file_prefix', None), kargs.get('read_aux', False))
         elif len(arg) > 0:
             raise Exception("Invalid argument list")
 
@@ -60,16 +60,22 @@ class Solution(object):
         from . import io
         formats = format if isinstance(format, (list, tuple)) else [format]
         for fmt in formats:
-            if fmt != 'ascii':
-                raise NotImplementedError("pyclaw_amd writes the Clawpack ascii format only")
-            io.write_ascii(self, frame, path, file_prefix or 'fort', write_aux, options, write_p)
+            if fmt == 'ascii':
+                io.write_ascii(self, frame, path, file_prefix or 'fort', write_aux, options, write_p)
+            elif fmt == 'block':      # checkpoint: raw float64 block per rank + JSON header (io/block.py)
+                io.write_block(self, frame, path, file_prefix or 'claw', write_aux, options, write_p)
+            else:
+                raise NotImplementedError("pyclaw_amd writes the formats 'ascii' and 'block'")
 
     def read(self, frame, path='./', format='ascii', file_prefix=None, read_aux=True, options={}):
         """solution.py:406-448 (ascii only)"""
         from . import io
-        if format != 'ascii':
-            raise NotImplementedError("pyclaw_amd reads the Clawpack ascii format only")
-        io.read_ascii(self, frame, path, file_prefix or 'fort', read_aux, options)
+        if format == 'ascii':
+            io.read_ascii(self, frame, path, file_prefix or 'fort', read_aux, options)
+        elif format == 'block':
+            io.read_block(self, frame, path, file_prefix or 'claw', read_aux, options)
+        else:
+            raise NotImplementedError("pyclaw_amd reads the formats 'ascii' and 'block'")
 
     def __deepcopy__(self, memo={}):
         import copy

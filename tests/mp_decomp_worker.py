@@ -90,11 +90,43 @@ def local_bcs(qbc, g, bc_lower, bc_upper, user_lower, dec, nglob):
                 v[:, -g:, ...] = v[:, g:2 * g, ...]
 
 
+def field(meqn, I, J):
+    """deterministic global field q[m,i,j] (what every decomposition must reproduce)"""
+    m, i, j = np.meshgrid(np.arange(meqn), np.arange(I), np.arange(J), indexing="ij")
+    return np.asfortranarray(1000.0 * m + i + 0.001 * j + np.sin(0.1 * i * j))
+
+
+def checkpoint_case(outdir):
+    """every rank writes its block of a 37 x 29 state as a 'block' checkpoint, then reads the frame back
+    (same decomposition) through Solution(frame, format='block')"""
+    import pyclaw_amd as pyclaw
+    rank = parallel.rank()
+    grid = pyclaw.Grid([pyclaw.Dimension('x', 0., 1., 37), pyclaw.Dimension('y', -1., 1., 29)])
+    st = pyclaw.State(grid, 3, 2)
+    full, fa = field(3, 37, 29), field(2, 37, 29) * 0.5
+    (i0, i1), (j0, j1) = st.decomp.ranges
+    assert st.q.shape == (3, i1 - i0, j1 - j0)
+    st.q[...] = full[:, i0:i1, j0:j1]
+    st.aux[...] = fa[:, i0:i1, j0:j1]
+    st.t = 0.625
+    st.aux_global['gamma'] = 1.4
+    pyclaw.Solution(st).write(7, outdir, format='block', write_aux=True)
+    back = pyclaw.Solution(7, path=outdir, format='block', read_aux=True)
+    ok = (np.array_equal(back.state.q, st.q) and np.array_equal(back.state.aux, st.aux) and back.t == 0.625
+          and back.state.aux_global['gamma'] == 1.4)
+    print("RESULT case=checkpoint rank=%d equal=%s" % (rank, ok))
+    parallel.barrier()
+    parallel.shutdown()
+    sys.exit(0 if ok else 1)
+
+
 def main():
     case = sys.argv[1]
     nsteps = int(sys.argv[2])
     parallel.init("gloo")
     rank, size = parallel.rank(), parallel.world_size()
+    if case.startswith("checkpoint:"):
+        checkpoint_case(case.split(":", 1)[1])
     be = O.COracle()
 
     if case == "euler":

@@ -170,3 +170,31 @@ def test_controller_ascii_frames_and_gauges(tmp_path):
         series = {r[0]: r[1:] for r in rows}
         for kept in claw.frames:
             assert series[kept.t] == list(kept.state.q[:, g[0], g[1]])
+
+
+def test_restart_from_block_checkpoint(tmp_path):
+    """frames written as block checkpoints are restart points: a run restarted from frame 2
+    (Solution(frame, format='block') + Controller.start_frame) ends bit-equal to the uninterrupted run
+    (fixed dt, so both runs take the same steps)."""
+    import pyclaw_amd as pyclaw
+
+    def make(nout, tfinal):
+        claw = problems.acoustics2D(pyclaw, mx=50, my=40, nout=nout, tfinal=tfinal, run=False)
+        claw.solver.dt_variable = False
+        claw.solver.dt_initial = 0.003
+        claw.output_format = 'block'
+        claw.outdir = str(tmp_path)
+        return claw
+
+    full = make(4, 0.12)
+    full.run()
+    again = make(2, 0.12)
+    again.solution = pyclaw.Solution(2, path=str(tmp_path), format='block')
+    assert again.solution.t == full.frames[2].t
+    assert again.solution.state.aux_global['cc'] == 2.0          # problem scalars travel in the header
+    again.start_frame = 2
+    again.outdir = str(tmp_path / "restart")
+    again.run()
+    assert again.frames[-1].t == full.frames[4].t
+    assert np.array_equal(again.frames[-1].state.q, full.frames[4].state.q)
+    assert os.path.exists(os.path.join(again.outdir, "claw.ckpt0004.json"))

@@ -47,3 +47,17 @@ def test_2d_write_read(tmp_path):
     back = pyclaw.Solution(3, path=str(tmp_path), read_aux=True)
     assert np.array_equal(back.state.q, st.q) and back.t == 0.5
     assert np.array_equal(back.state.aux, st.aux)
+
+
+def test_block_checkpoint_roundtrip_and_restart_frame(tmp_path):
+    """1-D and 3-D shapes through the block format; a frame is a restart point (Controller.start_frame)."""
+    for dims, shape in (([pyclaw.Dimension('x', 0., 1., 11)], (2, 11)),
+                        ([pyclaw.Dimension('x', 0., 1., 5), pyclaw.Dimension('y', 0., 2., 4),
+                          pyclaw.Dimension('z', -1., 0., 3)], (2, 5, 4, 3))):
+        st = pyclaw.State(pyclaw.Grid(dims), 2)
+        st.q[...] = np.random.default_rng(len(shape)).standard_normal(shape)
+        st.t = 1.25
+        pyclaw.Solution(st).write(len(shape), str(tmp_path), format='block')
+        back = pyclaw.Solution(len(shape), path=str(tmp_path), format='block')
+        assert back.t == 1.25 and np.array_equal(back.state.q, st.q)
+        assert back.state.grid.n == st.grid.n and back.state.grid.upper == st.grid.upper

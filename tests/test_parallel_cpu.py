@@ -46,3 +46,23 @@ def test_four_ranks_equal_serial(case):
 def test_six_ranks_equal_serial():
     """the reference's own parallel tests use mpiexec -n 6 (test/util.py:64-95)"""
     run_workers(6, "acoustics_periodic")
+
+
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_checkpoint_written_by_n_ranks_restarts_on_one(nproc, tmp_path):
+    """block checkpoints (pyclaw_amd/io/block.py).  N ranks write their blocks and read
+    them back; then THIS single process reads the same frame and must get the whole field."""
+    import json
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    run_workers(nproc, "checkpoint:" + str(tmp_path))
+    import pyclaw_amd as pyclaw
+    from mp_decomp_worker import field
+    sol = pyclaw.Solution(7, path=str(tmp_path), format='block', read_aux=True)
+    assert sol.state.decomp is None and sol.t == 0.625
+    assert np.array_equal(sol.state.q, field(3, 37, 29))
+    assert np.array_equal(sol.state.aux, field(2, 37, 29) * 0.5)
+    hdr = json.load(open(os.path.join(str(tmp_path), "claw.ckpt0007.json")))
+    assert len(hdr["blocks"]) == nproc and hdr["n"] == [37, 29]
+    sizes = [os.path.getsize(os.path.join(str(tmp_path), b["file"])) for b in hdr["blocks"]]
+    assert sum(sizes) == 8 * (3 + 2) * 37 * 29          # raw float64, nothing else in the block files
