@@ -255,3 +255,57 @@ def advection1D(pyclaw, mx=1000, tfinal=1.0, nout=10):
     claw.nout = nout
     claw.run()
     return claw
+
+
+def acoustics3D(pyclaw, test='hom', mx=None, my=None, mz=None, run=True, math='exact', tfinal=2.0, nout=10):
+    """test/acoustics/3d/acoustics.py:6-96.  'hom': dim-split 256x4x4, all periodic (the reference gates
+    final_difference = 0.00286 +- 1e-4, test/test_examples.py:481-488); 'het' needs the unsplit step3."""
+    solver = pyclaw.ClawSolver3D()
+    solver.math = math
+    solver.rp = pyclaw.riemann.rp_vc_acoustics_3d
+    for k in range(3):
+        solver.bc_lower[k] = solver.bc_upper[k] = pyclaw.BC.periodic
+        solver.aux_bc_lower[k] = solver.aux_bc_upper[k] = pyclaw.BC.periodic
+    if test == 'hom':
+        solver.dim_split = True
+        mx, my, mz = mx or 256, my or 4, mz or 4
+        zr = cr = 1.0
+    else:
+        solver.dim_split = False
+        for k in range(3):
+            solver.bc_lower[k] = pyclaw.BC.reflecting
+            solver.aux_bc_lower[k] = pyclaw.BC.reflecting
+        mx, my, mz = mx or 30, my or 30, mz or 30
+        zr = cr = 2.0
+    solver.mwaves = 2
+    solver.limiters = pyclaw.limiters.tvd.MC
+    x = pyclaw.Dimension('x', -1.0, 1.0, mx)
+    y = pyclaw.Dimension('y', -1.0, 1.0, my)
+    z = pyclaw.Dimension('z', -1.0, 1.0, mz)
+    grid = pyclaw.Grid([x, y, z])
+    state = pyclaw.State(grid, 4, 2)
+    zl = cl = 1.0
+    grid.compute_c_center()
+    X, Y, Z = grid._c_center
+    state.aux[0, :, :, :] = zl * (X < 0.) + zr * (X >= 0.)
+    state.aux[1, :, :, :] = cl * (X < 0.) + cr * (X >= 0.)
+    x0, y0, z0 = -0.5, 0., 0.
+    if test == 'hom':
+        r = np.sqrt((X - x0) ** 2)
+        width = 0.2
+        state.q[0, :, :, :] = (np.abs(r) <= width) * (1. + np.cos(np.pi * r / width))
+    else:
+        r = np.sqrt((X - x0) ** 2 + (Y - y0) ** 2 + (Z - z0) ** 2)
+        width = 0.1
+        state.q[0, :, :, :] = (np.abs(r - 0.3) <= width) * (1. + np.cos(np.pi * (r - 0.3) / width))
+    state.q[1:, :, :, :] = 0.
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.solution = pyclaw.Solution(state)
+    claw.solver = solver
+    claw.tfinal = tfinal
+    claw.nout = nout
+    if not run:
+        return claw
+    claw.run()
+    return claw

@@ -45,6 +45,22 @@ def build(nx_global, ny_global, math, unsplit=False):
     return claw
 
 
+def build3d(n, math):
+    """3-D synthetic workload: the reference's 3-D acoustics app (test/acoustics/3d/acoustics.py, 'hom' set-up:
+    dim-split, periodic) on an n^3 grid with a two-material aux field."""
+    import pyclaw_amd as pyclaw
+    from apps import problems
+    claw = problems.acoustics3D(pyclaw, mx=n, my=n, mz=n, run=False, math=math)
+    st = claw.solution.state
+    X, Y, Z = st.grid.c_center
+    st.aux[0] = 1.0 + (X >= 0.)                     # impedance 1 | 2
+    st.aux[1] = 1.0 + (X >= 0.)                     # sound speed 1 | 2
+    r = np.sqrt((X + 0.5) ** 2 + Y ** 2 + Z ** 2)
+    st.q[0] = (np.abs(r - 0.3) <= 0.1) * (1. + np.cos(np.pi * (r - 0.3) / 0.1))
+    claw.solver.dt_initial = 0.4 * (2.0 / n) / 2.0
+    return claw
+
+
 def pmc_traffic(math, which, nx, ny):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_final_pmc_hbm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
@@ -105,6 +121,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=["exact", "fast"], default="exact")
     ap.add_argument("--unsplit", action="store_true", help="unsplit algorithm with order_trans=2 (not the headline)")
+    ap.add_argument("--ndim", type=int, default=2, choices=[2, 3],
+                    help="3: 3-D dim-split acoustics on an nx^3 grid (single GPU; not the headline)")
     args = ap.parse_args()
 
     from pyclaw_amd import parallel, _lib
@@ -116,9 +134,19 @@ def main():
                              % (args.gpus, size))
         sys.exit(2)
 
-    dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
-    nxg, nyg = args.nx * dims[0], args.ny * dims[1]
-    claw = build(nxg, nyg, args.math, args.unsplit)
+    if args.ndim == 3:
+        if size != 1:
+            sys.stderr.write("bench.py --ndim 3 runs on one GPU (3-D decomposition is not built yet)\n")
+            sys.exit(2)
+        if args.nx == 4096:
+            args.nx = 512
+        args.ny = args.nx
+        dims, nxg, nyg = [1, 1, 1], args.nx, args.nx
+        claw = build3d(args.nx, args.math)
+    else:
+        dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
+        nxg, nyg = args.nx * dims[0], args.ny * dims[1]
+        claw = build(nxg, nyg, args.math, args.unsplit)
     solver, solution = claw.solver, claw.solution
     solver.setup(solution)
     solver.dt = solver.dt_initial
@@ -152,7 +180,7 @@ def main():
     finite = bool(np.isfinite(q).all())
     solver.teardown()
 
-    cells_total = float(nxg) * float(nyg)
+    cells_total = float(nxg) * float(nyg) * (float(args.nx) if args.ndim == 3 else 1.0)
     value = cells_total * args.steps / elapsed / 1e6
 
     if rank == 0:
@@ -161,6 +189,10 @@ def main():
         avg = [ms[k] / max(1, nl[k]) for k in range(2)]
         dom = int(np.argmax(avg))
         bytes_launch = BYTES_PER_CELL_SWEEP * float(args.nx) * float(args.ny)
+        if args.ndim == 3:
+            # per directional sweep: read q (4) + aux (2), write q (4) doubles per cell
+            names = [ns + "sweep3_kernel<VcAcoustics3D, 1> (x sweep)", ns + "sweep3_kernel<VcAcoustics3D, 2|3> (y, z sweeps)"]
+            bytes_launch = (4 + 2 + 4) * 8 * float(args.nx) ** 3
         achieved = bytes_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         out = {
             "metric": "Mcell*steps/s, 2-D Euler classic dim-split step (+ achieved HBM GB/s in roofline)",
@@ -168,20 +200,24 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "apps/euler 2D shock-bubble, %dx%d cells per GPU, classic %s, "
+            "config": {"workload": ("test/acoustics/3d 3-D variable-coefficient acoustics, %d^3 cells, classic dim-split "
+                                    "(step3ds), MC limiter, order 2" % args.nx) if args.ndim == 3 else
+                                   "apps/euler 2D shock-bubble, %dx%d cells per GPU, classic %s, "
                                    "mthlim=[4,4,4,4,2], order 2, source off"
                                    % (args.nx, args.ny, "UNSPLIT order_trans=2" if args.unsplit else "dim-split"),
-                       "global_grid": [nxg, nyg], "proc_grid": dims, "math": ("exact (no FMA, IEEE div/sqrt; bit-identical to the reference)" if args.math == "exact"
+                       "global_grid": [nxg, nyg] + ([args.nx] if args.ndim == 3 else []), "proc_grid": dims, "math": ("exact (no FMA, IEEE div/sqrt; bit-identical to the reference)" if args.math == "exact"
                                 else "fast (FMA contraction, reciprocal-multiply division; rtol 1e-12 vs reference)"),
                        "launches": {names[0]: int(nl[0]), names[1]: int(nl[1])},
                        "steps_incl_rejected": int(nl[0]), "result_finite": finite},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.math, dom, args.nx, args.ny),
+                         "traffic": pmc_traffic(args.math, dom, args.nx, args.ny) if args.ndim == 2 else None,
                          "avg_ms": {names[0]: avg[0], names[1]: avg[1]},
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
-        if size == 1 and not args.no_cpu_baseline:
+        if args.ndim == 3:
+            out["metric"] = "Mcell*steps/s, 3-D acoustics classic dim-split step (+ achieved HBM GB/s in roofline)"
+        if size == 1 and not args.no_cpu_baseline and args.ndim == 2:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.nx, args.ny)
             except Exception as e:      # the oracle is optional infrastructure, never the product

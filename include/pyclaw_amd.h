@@ -51,6 +51,7 @@ extern "C" {
 #define PCL_RP_ACOUSTICS_1D 2 /* rp1_acoustics.f            cparam: rho,bulk,cc,zz      */
 #define PCL_RP_ACOUSTICS_2D 10 /* rpn2/rpt2_acoustics.f     cparam: rho,bulk,cc,zz      */
 #define PCL_RP_EULER5_2D 11    /* rpn2/rpt2_euler_5wave.f   cparam: gamma,gamma1        */
+#define PCL_RP_VC_ACOUSTICS_3D 20 /* rpn3_vc_acoustics.f (test/acoustics/3d/Makefile); aux(1)=Z, aux(2)=c; dim-split only */
 
 /* boundary condition types = pyclaw.BC (src/pyclaw/solver.py:17-23) */
 #define PCL_BC_CUSTOM 0
@@ -124,6 +125,14 @@ int pcl_step2(int rp, const double *rp_params, int fwave, int meqn, int mwaves, 
               int mbc, int mx, int my, const double *qold, double *qnew, const double *aux,
               double dx, double dy, double dt, const int *method, const int *mthlim,
               double *cfl);
+
+/* classic3.step3ds(maxm,mbc,mx,my,mz,qold,qnew,aux,dx,dy,dz,dt,method,mthlim,aux1,aux2,aux3,work,idir)
+ * -> (qnew,cfl)   src/fortran/3d/classic/step3ds.f:2-5, clawpack.py:678-688: one directional sweep
+ * (idir 1..3) of the dimension-split 3-D algorithm; q(m,i,j,k) component fastest, ghost cells included;
+ * slices with transverse indices 0..m+1 are swept, everything else is returned unchanged. */
+int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx, int my,
+                int mz, const double *qold, double *qnew, const double *aux, double dx, double dy, double dz,
+                double dt, const int *method, const int *mthlim, double *cfl, int idir);
 
 /* sharpclaw1.flux1(q,aux,dt,t,ixy,mx,mbc,maxnx) -> (dq,cfl)   1d/sharpclaw/flux1.f90, sharpclaw.py:385
  * sharpclaw2.flux2(q,aux,dt,t,mbc,maxm,mx,my)   -> (dq,cfl)   2d/sharpclaw/flux2.f90:2, sharpclaw.py:558

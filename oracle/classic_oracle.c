@@ -21,10 +21,15 @@
  *   step2       src/fortran/2d/classic/step2.f:2-241
  *   rpn2 Euler  development/rp_approaches/rpn2_euler_5wave.f:5-302
  *   rpt2 Euler  development/rp_approaches/rpt2_euler_5wave_rec_loc.f:4-121
+ *   flux3       src/fortran/3d/classic/flux3.f:168-258   (normal solve, CFL, correction: the part the
+ *                                                          dimension-split algorithm uses, method(3)<0)
+ *   step3ds     src/fortran/3d/classic/step3ds.f:108-374
  * Riemann solvers whose source is NOT in the reference tree (third-party
  * clawpack/riemann, unpinned; named in the app Makefiles only) are restated
  * from their published algorithm: rp1_advection, rp1_acoustics,
- * rpn2_acoustics, rpt2_acoustics.  rpn2_acoustics is pinned through the
+ * rpn2_acoustics, rpt2_acoustics, rpn3_vc_acoustics (the reference's test/acoustics/3d/Makefile names
+ * $(RIEMANN)/src/rpn3_vc_acoustics.f; pinned only through the scalar result 0.00286 +- 1e-4 of
+ * test_3D_acoustics_homogeneous, test/test_examples.py:481-488).  rpn2_acoustics is pinned through the
  * reference golden test/acoustics2D_solution; the others are "parity
  * unpinned" at the Riemann-solver boundary.
  *
@@ -39,6 +44,7 @@
 #define RP_ACOUSTICS_1D 2
 #define RP_ACOUSTICS_2D 10
 #define RP_EULER5_2D 11
+#define RP_VC_ACOUSTICS_3D 20
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 static inline double dmin(double a, double b) { return a < b ? a : b; }
@@ -791,3 +797,137 @@ void orc_limiter(int meqn, int mwaves, int mbc, int mx, double *wave, const doub
 }
 
 double orc_philim(double a, double b, int meth) { return philim(a, b, meth); }
+
+
+/* ======================================================================== 3-D, dimension split */
+/* variable-coefficient acoustics in 3-D, restated (third-party rpn3_vc_acoustics.f):
+ * q = (p,u,v,w); aux(1) = impedance Z, aux(2) = sound speed c of each cell; two waves. */
+static void rpn3_vc_acoustics(int ixyz, int meqn, int mwaves, int maux, int mbc, int mx,
+                              const double *ql, const double *qr, const double *auxl, const double *auxr,
+                              double *wave, double *s, double *amdq, double *apdq)
+{
+#define AX(arr, ma, i) arr[((ma)-1) + maux * IX(i)]
+    int mu = ixyz + 1;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        double d1 = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        double d2 = A2(ql, mu, i) - A2(qr, mu, i - 1);
+        double zi = AX(auxl, 1, i), zim = AX(auxr, 1, i - 1);
+        double a1 = (-d1 + zi * d2) / (zim + zi);
+        double a2 = (d1 + zim * d2) / (zim + zi);
+        for (int m = 1; m <= meqn; m++) { W(m, 1, i) = 0.0; W(m, 2, i) = 0.0; }
+        W(1, 1, i) = -a1 * zim;
+        W(mu, 1, i) = a1;
+        S(1, i) = -AX(auxr, 2, i - 1);
+        W(1, 2, i) = a2 * zi;
+        W(mu, 2, i) = a2;
+        S(2, i) = AX(auxl, 2, i);
+    }
+    for (int m = 1; m <= meqn; m++)
+        for (int i = 2 - mbc; i <= mx + mbc; i++) {
+            A2(amdq, m, i) = S(1, i) * W(m, 1, i);
+            A2(apdq, m, i) = S(2, i) * W(m, 2, i);
+        }
+#undef AX
+}
+
+/* flux3.f:168-258 with method(3) < 0 (m3 = -1: returns before the transverse part).
+ * aux1d = aux2(:, :, 2) of the caller: the slice's own aux values. */
+static int flux3_split(int rp, int ixyz, int meqn, int mwaves, int maux, int mbc, int mx,
+                       const int *method, const int *mthlim, work_t *w, const double *aux1d,
+                       double *cfl1d_out)
+{
+    double *wave = w->wave, *s = w->s, *amdq = w->amdq, *apdq = w->apdq, *cqxx = w->cqxx;
+    double *q1d = w->q1d, *qadd = w->qadd, *fadd = w->fadd, *dtdx1d = w->dtdx1d;
+#define DT(i) dtdx1d[IX(i)]
+    int limit = 0;
+    for (int mw = 0; mw < mwaves; mw++)
+        if (mthlim[mw] > 0) limit = 1;
+    for (int i = 1 - mbc; i <= mx + mbc; i++)
+        for (int m = 1; m <= meqn; m++) { A2(qadd, m, i) = 0.0; A2(fadd, m, i) = 0.0; }
+    if (rp != RP_VC_ACOUSTICS_3D) return -1;
+    rpn3_vc_acoustics(ixyz, meqn, mwaves, maux, mbc, mx, q1d, q1d, aux1d, aux1d, wave, s, amdq, apdq);
+    /* forall, flux3.f:205-208: all apdq terms, then all amdq terms */
+    for (int i = 1; i <= mx + 1; i++)
+        for (int m = 1; m <= meqn; m++) A2(qadd, m, i) = A2(qadd, m, i) - DT(i) * A2(apdq, m, i);
+    for (int i = 1; i <= mx + 1; i++)
+        for (int m = 1; m <= meqn; m++) A2(qadd, m, i - 1) = A2(qadd, m, i - 1) - DT(i - 1) * A2(amdq, m, i);
+    double cfl1d = 0.0;
+    for (int i = 1; i <= mx + 1; i++)
+        for (int mw = 1; mw <= mwaves; mw++)
+            cfl1d = dmax(dmax(cfl1d, DT(i) * S(mw, i)), -DT(i - 1) * S(mw, i));
+    *cfl1d_out = cfl1d;
+    if (method[1] != 1) {
+        if (limit) limiter(meqn, mwaves, mbc, mx, wave, s, mthlim);
+        for (int i = 2 - mbc; i <= mx + mbc; i++) {
+            double dtdxave = 0.5 * (DT(i - 1) + DT(i));
+            for (int m = 1; m <= meqn; m++) A2(cqxx, m, i) = 0.0;
+            for (int mw = 1; mw <= mwaves; mw++)
+                for (int m = 1; m <= meqn; m++)   /* flux3.f:244-247: 0.5 inside every term */
+                    A2(cqxx, m, i) = A2(cqxx, m, i) +
+                                     0.5 * fabs(S(mw, i)) * (1.0 - fabs(S(mw, i)) * dtdxave) * W(m, mw, i);
+            for (int m = 1; m <= meqn; m++) A2(fadd, m, i) = A2(fadd, m, i) + A2(cqxx, m, i);
+        }
+    }
+    if (method[2] >= 0) return -2;   /* unsplit 3-D (rpt3/rptt3) is not restated */
+    return 0;
+#undef DT
+}
+
+#define Q4(arr, m, i, j, k)                                                                            \
+    arr[((m)-1) + (size_t)meqn * (((i) + mbc - 1) + (size_t)(mx + 2 * mbc) * (((j) + mbc - 1) +          \
+                                                      (size_t)(my + 2 * mbc) * ((k) + mbc - 1)))]
+#define AUX4(ma, i, j, k)                                                                              \
+    aux[((ma)-1) + (size_t)maux * (((i) + mbc - 1) + (size_t)(mx + 2 * mbc) * (((j) + mbc - 1) +         \
+                                                      (size_t)(my + 2 * mbc) * ((k) + mbc - 1)))]
+
+/* step3ds.f:108-374.  qold may alias qnew (2nd and 3rd call of the dim-split step, clawpack.py:682-688). */
+int orc_step3ds(int rp, int maxm, int meqn, int mwaves, int maux, int mbc, int mx, int my, int mz,
+                const double *qold, double *qnew, const double *aux, double dx, double dy, double dz,
+                double dt, const int *method, const int *mthlim, double *cfl_out, int idir)
+{
+    work_t w;
+    work_alloc(&w, maxm, mbc, meqn, mwaves);
+    double *q1d = w.q1d, *qadd = w.qadd, *fadd = w.fadd, *dtdx1d = w.dtdx1d;
+    double *aux1d = calloc((size_t)(maxm + 2 * mbc) * (maux > 0 ? maux : 1), sizeof(double));
+    int mcapa = method[5];
+    double cfl = 0.0, cfl1d = 0.0;
+    const double dtd[3] = {dt / dx, dt / dy, dt / dz};
+    const int n[3] = {mx, my, mz};
+    int rc = 0;
+    const int d = idir - 1, nd = n[d];
+    /* the two transverse directions (outer, inner loop of the Fortran): x: k,j   y: k,i   z: j,i */
+    const int o = idir == 3 ? 1 : 2, in = idir == 1 ? 1 : 0;
+    if (mcapa == 0)
+        for (int i = 1 - mbc; i <= maxm + mbc; i++) dtdx1d[IX(i)] = dtd[d];
+    for (int a = 0; a <= n[o] + 1; a++)
+        for (int b = 0; b <= n[in] + 1; b++) {
+            int c[3];
+#define CELL(t) (c[d] = (t), c[o] = a, c[in] = b)
+            for (int t = 1 - mbc; t <= nd + mbc; t++) {
+                CELL(t);
+                for (int m = 1; m <= meqn; m++) A2(q1d, m, t) = Q4(qold, m, c[0], c[1], c[2]);
+                if (mcapa > 0) dtdx1d[IX(t)] = dtd[d] / AUX4(mcapa, c[0], c[1], c[2]);
+                for (int ma = 1; ma <= maux; ma++) aux1d[(ma - 1) + maux * IX(t)] = AUX4(ma, c[0], c[1], c[2]);
+            }
+            int r = flux3_split(rp, idir, meqn, mwaves, maux, mbc, nd, method, mthlim, &w, aux1d, &cfl1d);
+            if (r) rc = r;
+            cfl = dmax(cfl, cfl1d);
+            for (int t = 1; t <= nd; t++) {
+                CELL(t);
+                for (int m = 1; m <= meqn; m++) {
+                    if (mcapa == 0)
+                        Q4(qnew, m, c[0], c[1], c[2]) = Q4(qnew, m, c[0], c[1], c[2]) + A2(qadd, m, t) -
+                                                        dtd[d] * (A2(fadd, m, t + 1) - A2(fadd, m, t));
+                    else
+                        Q4(qnew, m, c[0], c[1], c[2]) = Q4(qnew, m, c[0], c[1], c[2]) + A2(qadd, m, t) -
+                                                        dtd[d] * (A2(fadd, m, t + 1) - A2(fadd, m, t)) /
+                                                            AUX4(mcapa, c[0], c[1], c[2]);
+                }
+            }
+#undef CELL
+        }
+    *cfl_out = cfl;
+    free(aux1d);
+    work_free(&w);
+    return rc;
+}

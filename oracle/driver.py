@@ -152,6 +152,19 @@ def step_hyperbolic(p, backend):
         mx = p.q.shape[1]
         _, cfl = backend.step1(p.rp, p.rp_params, mbc, mx, p.qbc, p.auxbc, p.d[0], p.dt,
                                p.method, p.mthlim)
+    elif p.ndim == 3:                                       # clawpack.py:650-699 (dim_split only)
+        mx, my, mz = p.q.shape[1:]
+        maxm = max(mx, my, mz)
+        qnew = p.qbc
+        qold = qnew.copy("F")
+        dx, dy, dz = p.d
+        if not p.dim_split:
+            raise NotImplementedError("unsplit 3-D (step3) is not restated")
+        cfl = 0.0
+        for idir, qo in ((1, qold), (2, qnew), (3, qnew)):
+            _, c1 = backend.step3ds(p.rp, maxm, mbc, mx, my, mz, qo, qnew, p.auxbc, dx, dy, dz, p.dt,
+                                    p.method, p.mthlim, idir)
+            cfl = max(cfl, c1)
     else:
         mx, my = p.q.shape[1:]
         maxm = max(mx, my)
@@ -428,3 +441,38 @@ def advection1d_problem(mx=1000, u=1.0, beta=100.0, x0=0.75):
         q=q, d=(1.0 / float(mx),), rp=RP_ADVECTION_1D, rp_params=[u], mwaves=1, limiters=[1],
         cfl_max=1.0, cfl_desired=0.9, dt_initial=0.1,
         bc_lower=[PERIODIC], bc_upper=[PERIODIC])
+
+
+def acoustics3d_problem(test='hom', mx=None, my=None, mz=None, **kw):
+    """test/acoustics/3d/acoustics.py:6-96 ('hom': dim-split, 256x4x4, all periodic)."""
+    if test == 'hom':
+        n = (mx or 256, my or 4, mz or 4)
+        zr = cr = 1.0
+        bc_lower = [PERIODIC] * 3
+        dim_split = True
+    else:
+        n = (mx or 30, my or 30, mz or 30)
+        zr = cr = 2.0
+        bc_lower = [REFLECTING] * 3
+        dim_split = False
+    zl = cl = 1.0
+    c = [centers(-1.0, 1.0, k) for k in n]
+    X, Y, Z = np.meshgrid(c[0], c[1], c[2], indexing="ij")
+    aux = np.empty((2,) + n, order="F")
+    aux[0] = zl * (X < 0.) + zr * (X >= 0.)
+    aux[1] = cl * (X < 0.) + cr * (X >= 0.)
+    q = np.zeros((4,) + n, order="F")
+    x0, y0, z0 = -0.5, 0., 0.
+    if test == 'hom':
+        r = np.sqrt((X - x0) ** 2)
+        width = 0.2
+        q[0] = (np.abs(r) <= width) * (1. + np.cos(np.pi * r / width))
+    else:
+        r = np.sqrt((X - x0) ** 2 + (Y - y0) ** 2 + (Z - z0) ** 2)
+        width = 0.1
+        q[0] = (np.abs(r - 0.3) <= width) * (1. + np.cos(np.pi * (r - 0.3) / width))
+    from . import oracle as O
+    return Problem(q=q, aux=aux, rp=O.RP_VC_ACOUSTICS_3D, rp_params=np.zeros(8), mwaves=2, limiters=4,
+                   bc_lower=bc_lower, bc_upper=[PERIODIC] * 3, aux_bc_lower=list(bc_lower),
+                   aux_bc_upper=[PERIODIC] * 3, d=tuple(2.0 / k for k in n), dim_split=dim_split,
+                   order_trans=22, **kw)

@@ -25,6 +25,7 @@ RP_ADVECTION_1D = 1
 RP_ACOUSTICS_1D = 2
 RP_ACOUSTICS_2D = 10
 RP_EULER5_2D = 11
+RP_VC_ACOUSTICS_3D = 20
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -58,6 +59,8 @@ class COracle:
                                   C.c_double, _ip, _ip, _dp, C.c_int]
         L.orc_step2.restype = C.c_int
         L.orc_step2.argtypes = L.orc_step2ds.argtypes[:-1]
+        L.orc_step3ds.restype = C.c_int
+        L.orc_step3ds.argtypes = [C.c_int] * 9 + [_dp, _dp, _dp] + [C.c_double] * 4 + [_ip, _ip, _dp, C.c_int]
         L.orc_step1.restype = C.c_int
         L.orc_step1.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
                                 C.c_double, C.c_double, _ip, _ip, _dp]
@@ -96,6 +99,21 @@ class COracle:
                                   C.byref(cfl), ids)
         if rc:
             raise RuntimeError("oracle: unknown Riemann solver id %d" % rp)
+        return qnew, cfl.value
+
+    def step3ds(self, rp, maxm, mbc, mx, my, mz, qold, qnew, aux, dx, dy, dz, dt, method, mthlim, idir):
+        """classic3.step3ds(...) -> (qnew, cfl) (clawpack.py:678-688); qnew in place, may alias qold."""
+        meqn = qnew.shape[0]
+        method = np.ascontiguousarray(method, dtype=np.int32)
+        mthlim = np.ascontiguousarray(mthlim, dtype=np.int32)
+        maux = int(method[6])
+        auxp = _d(aux) if (aux is not None and maux > 0) else _d(np.zeros(1))
+        cfl = C.c_double(0.0)
+        assert qnew.flags.f_contiguous and qold.flags.f_contiguous
+        rc = self.lib.orc_step3ds(rp, maxm, meqn, len(mthlim), maux, mbc, mx, my, mz, _d(qold), _d(qnew), auxp,
+                                  dx, dy, dz, dt, _i(method), _i(mthlim), C.byref(cfl), idir)
+        if rc:
+            raise RuntimeError("oracle step3ds: rc=%d (unknown Riemann solver / unsplit 3-D not restated)" % rc)
         return qnew, cfl.value
 
     def step2(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim,

@@ -2,13 +2,13 @@
 pyclaw_amd -- MI355X-native implementation of PyClaw's data-parallel hot path.
 
 Same class names and solver surface as the reference package (``import pyclaw_amd as pyclaw``):
-Dimension, Grid, State, Solution, BC, ClawSolver1D/2D, SharpClawSolver1D/2D, Controller.  The classic
+Dimension, Grid, State, Solution, BC, ClawSolver1D/2D/3D, SharpClawSolver1D/2D, Controller.  The classic
 wave-propagation step runs in hand-written HIP kernels (libpyclaw_amd.so, include/pyclaw_amd.h);
 there is no CPU fallback.
 """
-from . import riemann
+from . import limiters, riemann
 from .cfl import CFL
-from .clawpack import ClawSolver1D, ClawSolver2D, DeviceSource, EulerRadialSource
+from .clawpack import ClawSolver1D, ClawSolver2D, ClawSolver3D, DeviceSource, EulerRadialSource
 from .controller import Controller
 from .grid import Dimension, Grid
 from .sharpclaw import SharpClawSolver1D, SharpClawSolver2D
@@ -16,5 +16,5 @@ from .solution import Solution
 from .solver import BC, ConstantStateBC, DeviceBC
 from .state import State
 
-__all__ = ['riemann', 'CFL', 'ClawSolver1D', 'ClawSolver2D', 'DeviceSource', 'EulerRadialSource',
+__all__ = ['limiters', 'riemann', 'CFL', 'ClawSolver1D', 'ClawSolver2D', 'ClawSolver3D', 'DeviceSource', 'EulerRadialSource',
            'Controller', 'SharpClawSolver1D', 'SharpClawSolver2D', 'Dimension', 'Grid', 'Solution', 'BC', 'ConstantStateBC', 'DeviceBC', 'State']

@@ -248,3 +248,24 @@ class ClawSolver2D(ClawSolver):
             import warnings
             warnings.warn('cfl_max is set higher than the recommended value of %s' % cfl_recommended)
             warnings.warn(str(self.cfl_desired))
+
+
+class ClawSolver3D(ClawSolver):
+    r"""3D classic solver (clawpack.py:563-702).  ``dim_split=True`` (Godunov splitting, ``step3ds``) runs on
+    the device; the unsplit algorithm with ``rpt3``/``rptt3`` transverse solves is not built yet."""
+
+    no_trans = 0
+    trans_inc = 11
+    trans_cor = 22
+
+    def __init__(self, data=None):
+        self._default_attr_values['dim_split'] = True
+        self._default_attr_values['order_trans'] = self.trans_cor
+        self.ndim = 3
+        super(ClawSolver3D, self).__init__(data)
+
+    def setup(self, solution):
+        if not self.dim_split:
+            raise NotImplementedError("pyclaw_amd ClawSolver3D implements dim_split=True (step3ds); "
+                                      "the unsplit step3 with rpt3/rptt3 is not built")
+        super(ClawSolver3D, self).setup(solution)

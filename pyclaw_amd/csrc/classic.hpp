@@ -105,15 +105,21 @@ __device__ __forceinline__ void cfl_publish(unsigned long long *word, double v) 
 // TRANS (unsplit algorithm, flux2.f:151-189): instead of the updated cell, return the slice's
 // pieces for this cell -- qn := qadd, df := fadd(i+1)-fadd(i), g1/g2 := gadd(.,1,i), gadd(.,2,i)
 // (transverse flux corrections from rpt2 of amdq at interface i+1 and of apdq at interface i).
-template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = false>
+// F3 (3-D, flux3.f:236-252 + step3ds.f:177-181): correction coefficients carry the 0.5 like the 1-D code
+// (fadd = cqxx), the update is associated like the 2-D one ((q + qadd) - dtdx*(fadd(i+1)-fadd(i))).
+// auxv: this cell's aux values for Riemann solvers with RP::NAUX > 0.
+template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = false, bool F3 = false>
 __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dtdx_c, double capa,
                                           bool cfl_ok, const SweepArgs &a,
                                           double (&qn)[RP::MEQN], double &cflmax,
-                                          double *df = nullptr, double *g1 = nullptr, double *g2 = nullptr) {
+                                          double *df = nullptr, double *g1 = nullptr, double *g2 = nullptr,
+                                          const double *auxv = nullptr) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     using Cell = typename RP::Cell;
 
-    const Cell cR = RP::template precell<IXY>(q, a.par);
+    Cell cR;
+    if constexpr (RP::NAUX > 0) cR = RP::template precell<IXY>(q, a.par, auxv);
+    else cR = RP::template precell<IXY>(q, a.par);
     const Cell cL = struct_from_left(cR);
     const double dtdx_l = CAPA ? from_left(dtdx_c) : dtdx_c;
 
@@ -175,7 +181,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
 #pragma unroll
         for (int mw = 0; mw < MWAVES; mw++) {
             const double sa = fabs(s[mw]);
-            if (DIM1)
+            if (DIM1 || F3)
                 coef[mw] = 0.5 * sa * (1.0 - sa * dtdxave);
             else if (FWAVE)
                 coef[mw] = copysign(1.0, s[mw]) * (1.0 - sa * dtdxave);
@@ -193,7 +199,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                     first = false;
                 }
             cq[m] = c;
-            fadd[m] = DIM1 ? c : 0.5 * c;
+            fadd[m] = (DIM1 || F3) ? c : 0.5 * c;
         }
     }
 
@@ -688,6 +694,85 @@ __global__ __launch_bounds__(256) void combine_kernel(CombineArgs c) {
         }
         c.qnew[at] = q;
     }
+}
+
+// ---- 3-D dimension-split sweep (step3ds.f:108-374 + flux3.f:168-258) ---------------------------------
+// One kernel for the three directions: DIR = 1 (along i, memory-contiguous), 2 (along j), 3 (along k).
+// The array is q[m][k][j][i]; a launch describes the sweep by strides: s_al (along the sweep), s_ac (the
+// "across" index that shares a tile) and s_b (the batch index, blockIdx.y).  Tile = 64 cells along x 16
+// across, one lane per cell like the 2-D kernel; along-contiguous tiles sit in LDS as [ac][al], the others
+// as [al][ac] with pitch 17 (coalesced 128-byte row segments in, conflict-free column reads out).
+// Slices are swept only for transverse indices 0..m+1 (one ghost layer, step3ds.f:110-111,176-177,245-246);
+// every other cell is copied through, so the output array is complete.
+// First version: correct and coalesced, not yet tuned like the 2-D kernel (unaligned row pieces in DIR 1).
+template <class RP, int DIR>
+__global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac, int ntiles_al) {
+    constexpr int MEQN = RP::MEQN, NAUX = RP::NAUX, NP = MEQN + NAUX;
+    constexpr int AC = 16, PITCH = DIR == 1 ? WAVE : AC + 1;
+    constexpr int PLANE = DIR == 1 ? AC * WAVE : WAVE * (AC + 1);
+    __shared__ double tile[NP * PLANE];
+    auto at = [](int m, int al, int ac) { return m * PLANE + (DIR == 1 ? ac * PITCH + al : al * PITCH + ac); };
+
+    const int tb = DIR == 1 ? blockIdx.x / ntiles_al : blockIdx.x % ntiles_ac;
+    const int ta = DIR == 1 ? blockIdx.x % ntiles_al : blockIdx.x / ntiles_ac;
+    const int bt = blockIdx.y;
+    const int b0 = tb * AC, a0 = a.mbc - HALO + ta * STRIP;
+    const long base = (long)bt * a.s_b;
+
+    // cooperative load: memory-contiguous index fastest across the threads
+    const int l_al = DIR == 1 ? threadIdx.x % WAVE : threadIdx.x / AC;
+    const int l_ac = DIR == 1 ? threadIdx.x / WAVE : threadIdx.x % AC;
+    constexpr int STEP_AL = DIR == 1 ? 0 : 256 / AC, STEP_AC = DIR == 1 ? 256 / WAVE : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
+        int ga = a0 + al, gb = b0 + ac;
+        ga = ga < a.n_al ? ga : a.n_al - 1;
+        gb = gb < a.n_ac ? gb : a.n_ac - 1;
+        const long g = base + (long)ga * a.s_al + (long)gb * a.s_ac;
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) tile[at(m, al, ac)] = a.qin[m * a.plane + g];
+#pragma unroll
+        for (int m = 0; m < NAUX; m++) tile[at(MEQN + m, al, ac)] = a.aux[m * a.plane + g];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const int ca = a0 + lane;
+    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.m_al) && lane >= HALO && lane < WAVE - HALO;
+    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
+    const bool batch_live = bt >= a.lo_b && bt <= a.hi_b;
+    double cflmax = 0.0;
+    for (int ac = wv; ac < AC; ac += 256 / WAVE) {
+        const int gb = b0 + ac;
+        if (!batch_live || gb < a.lo_ac || gb > a.hi_ac) continue;  // wave-uniform: slice not swept
+        double q[MEQN], qn[MEQN], auxv[NAUX > 0 ? NAUX : 1];
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) q[m] = tile[at(m, lane, ac)];
+#pragma unroll
+        for (int m = 0; m < NAUX; m++) auxv[m] = tile[at(MEQN + m, lane, ac)];
+        lane_core<RP, DIR, false, false, false, false, true>(q, a.dtd, 1.0, cfl_ok, a, qn, cflmax, nullptr, nullptr,
+                                                             nullptr, auxv);
+        if (owned) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) tile[at(m, lane, ac)] = qn[m];
+        }
+    }
+    __syncthreads();
+
+    // cooperative store: cells this tile owns along the sweep + the ghost cells at the ends of the sweep
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
+        const int ga = a0 + al, gb = b0 + ac;
+        if (ga >= a.n_al || gb >= a.n_ac) continue;
+        const bool inner = (ga >= a.mbc) && (ga < a.mbc + a.m_al);
+        if (inner && (al < HALO || al >= WAVE - HALO)) continue;  // the neighbouring tile's cells
+        const long g = base + (long)ga * a.s_al + (long)gb * a.s_ac;
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[at(m, al, ac)];
+    }
+    cfl_publish(a.cfl, cflmax);
 }
 
 }  // namespace PCL_NS

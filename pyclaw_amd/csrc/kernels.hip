@@ -75,6 +75,21 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
     return PCL_EINVAL;
 }
 
+// 3-D dimension-split sweep along direction l.ids (classic.hpp: sweep3_kernel)
+int launch_sweep3(const SweepLaunch &l, std::string &err) {
+    const SweepArgs &a = l.a;
+    if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
+    if (l.rp != PCL_RP_VC_ACOUSTICS_3D) { err = "Riemann solver id is not a 3-D solver"; return PCL_EINVAL; }
+    if (a.mcapa > 0) { err = "3-D sweeps: capacity function not implemented"; return PCL_EINVAL; }
+    const int ntiles_ac = (a.n_ac + 15) / 16, ntiles_al = (a.m_al + STRIP - 1) / STRIP;
+    const dim3 grid((unsigned)ntiles_ac * (unsigned)ntiles_al, (unsigned)a.n_b);
+    if (l.ids == 1) hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 1>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
+    else if (l.ids == 2) hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 2>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
+    else hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 3>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep3 launch", e);
+}
+
 #if !PCL_FAST
 bool x_interior_box(const SweepArgs &a, int box[4]) {
     using T = TileShape<1>;

@@ -32,12 +32,12 @@ int fail(int code, const std::string &msg) {
 
 struct pcl_solver {
     pcl_config cfg;
-    int I = 1, J = 1;     // cells incl. ghosts
+    int I = 1, J = 1, K = 1;  // cells incl. ghosts (K > 1 only in 3-D: q[m][k][j][i], row r = k*J + j)
     long pitch = 0, plane = 0, total = 0;  // doubles
     long aplane = 0;
     int lead = 0;         // doubles the array bases are shifted by so that the first interior
                           // cell of every row starts a 128-byte line (16 - mbc)
-    double *q = nullptr, *t1 = nullptr, *t2 = nullptr, *bak = nullptr;
+    double *q = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *bak = nullptr;
     double *aux = nullptr;
     double *sreg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // SharpClaw registers (0 aliases q)
     int sel = 0;          // register the put/get/bc/strip/halo calls act on
@@ -75,22 +75,23 @@ using namespace pcl;
 
 // ---- layout conversion kernels: host Fortran AoS (m fastest) <-> device SoA planes ----
 // hostlike[(m) + meqn*(i + ni*j)] where (i,j) run over a window [io,io+ni) x [jo,jo+nj)
+// 3-D: blockIdx.z = k of the window, ko its offset, slab = doubles between k-planes (J*pitch).
 __global__ void aos_to_soa(const double *__restrict__ src, double *__restrict__ dst, int nm, int ni,
-                           int nj, int io, int jo, long pitch, long plane) {
+                           int nj, int io, int jo, long pitch, long plane, int ko = 0, long slab = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
+    const int j = blockIdx.y, k = blockIdx.z;
     if (i >= ni || j >= nj) return;
-    const long h = (long)nm * (i + (long)ni * j);
-    const long d = (long)(j + jo) * pitch + (i + io);
+    const long h = (long)nm * (i + (long)ni * (j + (long)nj * k));
+    const long d = (long)(k + ko) * slab + (long)(j + jo) * pitch + (i + io);
     for (int m = 0; m < nm; m++) dst[m * plane + d] = src[h + m];
 }
 __global__ void soa_to_aos(const double *__restrict__ src, double *__restrict__ dst, int nm, int ni,
-                           int nj, int io, int jo, long pitch, long plane) {
+                           int nj, int io, int jo, long pitch, long plane, int ko = 0, long slab = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
+    const int j = blockIdx.y, k = blockIdx.z;
     if (i >= ni || j >= nj) return;
-    const long h = (long)nm * (i + (long)ni * j);
-    const long d = (long)(j + jo) * pitch + (i + io);
+    const long h = (long)nm * (i + (long)ni * (j + (long)nj * k));
+    const long d = (long)(k + ko) * slab + (long)(j + jo) * pitch + (i + io);
     for (int m = 0; m < nm; m++) dst[h + m] = src[m * plane + d];
 }
 
@@ -128,6 +129,39 @@ __global__ void bc_kernel(double *q, int nm, int I, int J, long pitch, long plan
     const long s = idim == 0 ? (long)t * pitch + srck : (long)srck * pitch + t;
     const double v = q[m * plane + s];
     q[m * plane + d] = (sign < 0.0) ? -v : v;
+}
+
+// 3-D ghost fill: one thread per (component m, ghost layer g, transverse cell t) of side `side` of dimension
+// idim; n[] = extents with ghosts, st[] = strides in doubles.  Same rules as bc_kernel (solver.py:384-452).
+struct Dims3 { int n[3]; long st[3]; };
+__global__ void bc3_kernel(double *q, int nm, Dims3 D, long plane, int mbc, int idim, int side, int type,
+                           int is_aux) {
+    const int d1 = idim == 0 ? 1 : 0, d2 = idim == 2 ? 1 : 2;  // the two transverse dimensions
+    const long nt = (long)D.n[d1] * D.n[d2];
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nt * mbc * nm) return;
+    const int m = (int)(tid / (nt * mbc));
+    const long rem = tid % (nt * mbc);
+    const int g = (int)(rem / nt);
+    const long t = rem % nt;
+    const int t1 = (int)(t % D.n[d1]), t2 = (int)(t / D.n[d1]);
+    const int N = D.n[idim];
+    int dstk, srck;
+    bool neg = false;
+    if (side == 0) {
+        dstk = g;
+        if (type == PCL_BC_OUTFLOW) srck = mbc;
+        else if (type == PCL_BC_PERIODIC) srck = N - 2 * mbc + g;
+        else { srck = 2 * mbc - 1 - g; neg = (m == idim + 1 && !is_aux); }
+    } else {
+        dstk = N - 1 - g;
+        if (type == PCL_BC_OUTFLOW) srck = N - mbc - 1;
+        else if (type == PCL_BC_PERIODIC) srck = 2 * mbc - 1 - g;
+        else { srck = N - 2 * mbc + g; neg = (m == idim + 1 && !is_aux); }
+    }
+    const long tr = (long)t1 * D.st[d1] + (long)t2 * D.st[d2];
+    const double v = q[m * plane + tr + (long)srck * D.st[idim]];
+    q[m * plane + tr + (long)dstk * D.st[idim]] = neg ? -v : v;
 }
 
 // ---- Euler radial source, test/euler/2d/shockbubble.py:59-94 -------------------------------
@@ -245,6 +279,48 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
     if (rc) fail(rc, err);
     if (timed) {
         hipEventRecord(t.b, stream);
+        s->timed.push_back(t);
+        if (s->timed.size() >= 2048) drain_timing(s);
+    }
+    return rc;
+}
+
+// 3-D dimension-split sweep along dir (1..3), qin -> qout (step3ds.f; kernel in classic.hpp)
+int do_sweep3(pcl_solver *s, const double *qin, double *qout, int dir, double dt) {
+    SweepArgs a = make_args(s, qin, qout, 1, dt);
+    const int mbc = s->cfg.mbc;
+    const long st[3] = {1, s->pitch, s->pitch * s->J};
+    const int n[3] = {s->I, s->J, s->K};
+    // (along, across, batch): x: (i, j, k)   y: (j, i, k)   z: (k, i, j) -- "across" is i whenever it can be
+    const int al = dir - 1, ac = dir == 1 ? 1 : 0, bt = dir == 3 ? 1 : 2;
+    a.dtd = dt / s->cfg.d[al];
+    a.dx = s->cfg.d[al];
+    a.s_al = st[al]; a.s_ac = st[ac]; a.s_b = st[bt];
+    a.n_al = n[al]; a.n_ac = n[ac]; a.n_b = n[bt];
+    a.m_al = s->cfg.n[al];
+    a.lo_ac = mbc - 1; a.hi_ac = mbc + s->cfg.n[ac];   // slices 0..m+1: one ghost layer (step3ds.f:110-111)
+    a.lo_b = mbc - 1; a.hi_b = mbc + s->cfg.n[bt];
+    a.vbc_on = 0;
+    pcl_solver::Timed t{};
+    if (s->timing) {
+        t.a = get_event(s);
+        t.b = get_event(s);
+        t.which = dir == 1 ? 0 : 1;
+        t.count = true;
+        hipEventRecord(t.a, s->stream);
+    }
+    SweepLaunch l;
+    l.a = a;
+    l.ndim = 3;
+    l.rp = s->cfg.rp;
+    l.ids = dir;
+    l.fwave = s->cfg.fwave;
+    l.stream = s->stream;
+    std::string err;
+    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sweep3(l, err) : pcl::exact::launch_sweep3(l, err);
+    if (rc) fail(rc, err);
+    if (s->timing) {
+        hipEventRecord(t.b, s->stream);
         s->timed.push_back(t);
         if (s->timed.size() >= 2048) drain_timing(s);
     }
@@ -378,7 +454,7 @@ int pcl_device_count(void) {
 int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (!cfg || !out) return fail(PCL_EINVAL, "null argument");
     *out = nullptr;
-    if (cfg->ndim < 1 || cfg->ndim > 2) return fail(PCL_EINVAL, "ndim must be 1 or 2");
+    if (cfg->ndim < 1 || cfg->ndim > 3) return fail(PCL_EINVAL, "ndim must be 1, 2 or 3");
     if (cfg->kind == PCL_KIND_CLASSIC && cfg->mbc != 2)
         return fail(PCL_EINVAL, "classic kernels need mbc == 2 (reference default)");
     if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->mbc != 3)
@@ -394,6 +470,7 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     case PCL_RP_ACOUSTICS_1D: want_meqn = 2; want_mwaves = 2; want_ndim = 1; break;
     case PCL_RP_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
     case PCL_RP_EULER5_2D: want_meqn = 5; want_mwaves = 5; want_ndim = 2; break;
+    case PCL_RP_VC_ACOUSTICS_3D: want_meqn = 4; want_mwaves = 2; want_ndim = 3; break;
     default: return fail(PCL_EINVAL, "unknown Riemann solver id");
     }
     if (cfg->meqn != want_meqn || cfg->mwaves != want_mwaves || cfg->ndim != want_ndim)
@@ -401,6 +478,11 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     for (int d = 0; d < cfg->ndim; d++)
         if (cfg->n[d] < 1) return fail(PCL_EINVAL, "grid extent must be >= 1");
     if (cfg->method[5] < 0 || cfg->method[5] > cfg->maux) return fail(PCL_EINVAL, "mcapa out of range");
+    if (cfg->ndim == 3) {
+        if (cfg->kind != PCL_KIND_CLASSIC) return fail(PCL_EINVAL, "3-D: classic solver only (the reference has no 3-D SharpClaw)");
+        if (cfg->maux < 2) return fail(PCL_EINVAL, "rpn3_vc_acoustics needs aux(1)=impedance, aux(2)=sound speed");
+        if (cfg->method[5] != 0) return fail(PCL_EINVAL, "3-D: capacity function not implemented");
+    }
     if (int rc = check_device()) return rc;
     HIP_TRY(hipSetDevice(cfg->device));
 
@@ -408,8 +490,9 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     s->cfg = *cfg;
     s->I = cfg->n[0] + 2 * cfg->mbc;
     s->J = cfg->ndim > 1 ? cfg->n[1] + 2 * cfg->mbc : 1;
+    s->K = cfg->ndim > 2 ? cfg->n[2] + 2 * cfg->mbc : 1;
     s->pitch = ((long)s->I + 15) / 16 * 16;
-    s->plane = s->pitch * s->J;
+    s->plane = s->pitch * s->J * s->K;
     s->total = s->plane * cfg->meqn;
     const size_t qbytes = (size_t)s->total * sizeof(double);
     // every buffer is zero-filled ON THE SOLVER'S STREAM: a null-stream hipMemset is not
@@ -428,12 +511,13 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (cfg->kind == PCL_KIND_CLASSIC) {
         alloc(&s->t1, qbytes);
         if (cfg->ndim > 1) alloc(&s->t2, qbytes);
+        if (cfg->ndim > 2) alloc(&s->t3, qbytes);
     } else {
         for (int k = 1; k < 5; k++) alloc(&s->sreg[k], qbytes);
     }
     if (cfg->maux > 0) alloc(&s->aux, (size_t)s->plane * cfg->maux * sizeof(double));
     const int nmax = cfg->meqn > cfg->maux ? cfg->meqn : cfg->maux;
-    s->stage_bytes = (size_t)nmax * s->I * s->J * sizeof(double);
+    s->stage_bytes = (size_t)nmax * s->I * s->J * s->K * sizeof(double);
     alloc(&s->stage, s->stage_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&s->cfl_dev, 64);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->cfl_host, 64, hipHostMallocDefault);
@@ -462,7 +546,7 @@ void pcl_destroy(pcl_solver *s) {
     if (s->hstream) hipStreamDestroy(s->hstream);
     for (auto &t : s->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto &e : s->evpool) hipEventDestroy(e);
-    for (double *p : {s->q, s->t1, s->t2, s->bak, s->aux, s->stage})
+    for (double *p : {s->q, s->t1, s->t2, s->t3, s->bak, s->aux, s->stage})
         if (p) hipFree(p - s->lead);
     for (double *p : s->scr)
         if (p) hipFree(p - s->lead);
@@ -483,11 +567,13 @@ static int put_array(pcl_solver *s, const double *host, double *dev, int nm, int
     const int nj = s->cfg.ndim > 1 ? (with_ghosts ? s->J : s->cfg.n[1]) : 1;
     const int io = with_ghosts ? 0 : mbc;
     const int jo = (s->cfg.ndim > 1 && !with_ghosts) ? mbc : 0;
-    const size_t bytes = (size_t)nm * ni * nj * sizeof(double);
+    const int nk = s->cfg.ndim > 2 ? (with_ghosts ? s->K : s->cfg.n[2]) : 1;
+    const int ko = (s->cfg.ndim > 2 && !with_ghosts) ? mbc : 0;
+    const size_t bytes = (size_t)nm * ni * nj * nk * sizeof(double);
     HIP_TRY(hipMemcpyAsync(s->stage, host, bytes, hipMemcpyHostToDevice, s->stream));
-    dim3 grid((ni + 255) / 256, nj);
+    dim3 grid((ni + 255) / 256, nj, nk);
     hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, dev, nm, ni, nj, io, jo,
-                       s->pitch, s->plane);
+                       s->pitch, s->plane, ko, s->pitch * s->J);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PCL_OK;
@@ -515,10 +601,12 @@ int pcl_get_q(pcl_solver *s, double *host, int with_ghosts) {
     const int nj = s->cfg.ndim > 1 ? (with_ghosts ? s->J : s->cfg.n[1]) : 1;
     const int io = with_ghosts ? 0 : mbc;
     const int jo = (s->cfg.ndim > 1 && !with_ghosts) ? mbc : 0;
-    const size_t bytes = (size_t)nm * ni * nj * sizeof(double);
-    dim3 grid((ni + 255) / 256, nj);
+    const int nk = s->cfg.ndim > 2 ? (with_ghosts ? s->K : s->cfg.n[2]) : 1;
+    const int ko = (s->cfg.ndim > 2 && !with_ghosts) ? mbc : 0;
+    const size_t bytes = (size_t)nm * ni * nj * nk * sizeof(double);
+    dim3 grid((ni + 255) / 256, nj, nk);
     hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, cur(s), s->stage, nm, ni, nj, io, jo,
-                       s->pitch, s->plane);
+                       s->pitch, s->plane, ko, s->pitch * s->J);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -527,6 +615,7 @@ int pcl_get_q(pcl_solver *s, double *host, int with_ghosts) {
 
 static int strip_window(pcl_solver *s, int idim, int side, int width, int &ni, int &nj, int &io,
                         int &jo) {
+    if (s->cfg.ndim > 2) return fail(PCL_EINVAL, "custom-BC strips are implemented for 1-D/2-D");
     if (idim < 0 || idim >= s->cfg.ndim) return fail(PCL_EINVAL, "bad idim");
     const int N = idim == 0 ? s->I : s->J;
     if (width < 1 || width > N) return fail(PCL_EINVAL, "bad strip width");
@@ -580,6 +669,7 @@ __global__ void gather_cells_kernel(const double *q, const double *aux, const in
 
 int pcl_get_cells(pcl_solver *s, int ncell, const int *ij, double *q, double *aux) {
     if (!s || !ij || !q) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.ndim > 2) return fail(PCL_EINVAL, "pcl_get_cells is implemented for 1-D/2-D (the reference's gauges are (x,y) pairs)");
     if (ncell <= 0) return PCL_OK;
     const int nq = s->cfg.meqn, na = (aux && s->aux) ? s->cfg.maux : 0, per = nq + na;
     if (aux && s->cfg.maux > 0 && !s->aux) return fail(PCL_EINVAL, "pcl_get_cells: aux requested but never uploaded");
@@ -610,8 +700,18 @@ int pcl_get_cells(pcl_solver *s, int ncell, const int *ij, double *q, double *au
 static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate, bool aux = false) {
     pcl::RpParams cs;  // the constant state travels as a kernel argument: no copy, no sync
     for (int k = 0; k < 8; k++) cs.v[k] = (cstate && k < s->cfg.meqn) ? cstate[k] : 0.0;
-    const int nt = idim == 0 ? s->J : s->I;
     const int nm = aux ? s->cfg.maux : s->cfg.meqn;
+    if (s->cfg.ndim == 3) {
+        if (type == 100) return fail(PCL_EINVAL, "constant-state BC is implemented for 1-D/2-D");
+        Dims3 D{{s->I, s->J, s->K}, {1, s->pitch, s->pitch * s->J}};
+        const int d1 = idim == 0 ? 1 : 0, d2 = idim == 2 ? 1 : 2;
+        const long n3 = (long)D.n[d1] * D.n[d2] * s->cfg.mbc * nm;
+        hipLaunchKernelGGL(bc3_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, s->stream,
+                           aux ? s->aux : cur(s), nm, D, s->plane, s->cfg.mbc, idim, side, type, aux ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        return PCL_OK;
+    }
+    const int nt = idim == 0 ? s->J : s->I;
     const long n = (long)nt * s->cfg.mbc * nm;
     hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream,
                        aux ? s->aux : cur(s), nm, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, idim, side, type,
@@ -652,7 +752,8 @@ int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl) {
     if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     if (ids < 1 || ids > s->cfg.ndim) return fail(PCL_EINVAL, "bad ids");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    if (int rc = do_sweep(s, s->q, s->t1, ids, dt)) return bail(s, rc);
+    if (int rc = s->cfg.ndim == 3 ? do_sweep3(s, s->q, s->t1, ids, dt) : do_sweep(s, s->q, s->t1, ids, dt))
+        return bail(s, rc);
     std::swap(s->q, s->t1);
     s->undo_slot = &s->t1;
     return read_cfl(s, cfl);
@@ -662,7 +763,14 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    if (s->cfg.ndim == 1) {
+    if (s->cfg.ndim == 3) {  // Godunov splitting x, y, z (clawpack.py:674-690)
+        if (s->cfg.method[2] >= 0) return fail(PCL_EINVAL, "3-D: only dim_split=True (step3ds) is implemented");
+        if (int rc = do_sweep3(s, s->q, s->t1, 1, dt)) return bail(s, rc);
+        if (int rc = do_sweep3(s, s->t1, s->t2, 2, dt)) return bail(s, rc);
+        if (int rc = do_sweep3(s, s->t2, s->t3, 3, dt)) return bail(s, rc);
+        std::swap(s->q, s->t3);
+        s->undo_slot = &s->t3;
+    } else if (s->cfg.ndim == 1) {
         if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return bail(s, rc);
         std::swap(s->q, s->t1);
         s->undo_slot = &s->t1;
@@ -691,7 +799,7 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     }
     // Dimension-split steps (and 1-D): the first pass evaluates the boundary conditions while it
     // loads its tiles -- no ghost-fill launches (each costs ~5 us of launch latency per step).
-    const bool fused = s->cfg.meqn <= 8 && (s->cfg.ndim == 1 || s->cfg.method[2] < 0);
+    const bool fused = s->cfg.meqn <= 8 && (s->cfg.ndim == 1 || (s->cfg.ndim == 2 && s->cfg.method[2] < 0));
     // Decomposed dim-split 2-D step: the halo exchange runs on its own stream while the x pass does the
     // tiles that read no ghost cell; the rim tiles follow once the ghost frame has arrived.
     int box[4];
@@ -948,6 +1056,31 @@ int pcl_step2(int rp, const double *rp_params, int fwave, int meqn, int mwaves, 
     if (!method || method[2] < 0) return fail(PCL_EINVAL, "step2 needs method[2] >= 0 (unsplit)");
     return host_sweep(2, rp, rp_params, fwave, meqn, mwaves, maux, mbc, mx, my, qold, qnew, aux, dx, dy,
                       dt, method, mthlim, cfl, 0, true);
+}
+
+int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx, int my, int mz,
+                const double *qold, double *qnew, const double *aux, double dx, double dy, double dz, double dt,
+                const int *method, const int *mthlim, double *cfl, int idir) {
+    if (!qold || !qnew || !method || !mthlim || !cfl) return fail(PCL_EINVAL, "null argument");
+    if (idir < 1 || idir > 3) return fail(PCL_EINVAL, "idir must be 1, 2 or 3");
+    if (mwaves < 1 || mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
+    pcl_config c;
+    memset(&c, 0, sizeof(c));
+    c.ndim = 3; c.n[0] = mx; c.n[1] = my; c.n[2] = mz; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves;
+    c.maux = maux;
+    for (int k = 0; k < 7; k++) c.method[k] = method[k];
+    for (int k = 0; k < mwaves; k++) c.mthlim[k] = mthlim[k];
+    c.rp = rp;
+    if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
+    c.d[0] = dx; c.d[1] = dy; c.d[2] = dz; c.math = PCL_MATH_EXACT;
+    pcl_solver *s = nullptr;
+    if (int rc = pcl_create(&c, &s)) return rc;
+    int rc = pcl_put_q(s, qold, 1);
+    if (!rc && maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
+    if (!rc) rc = pcl_sweep(s, idir, dt, cfl);
+    if (!rc) rc = pcl_get_q(s, qnew, 1);
+    pcl_destroy(s);
+    return rc;
 }
 
 static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux,

@@ -100,7 +100,7 @@ __device__ __forceinline__ double fdiv_ieee(double n, double d) {
 // 1-D advection, q_t + u q_x = 0  (third-party rp1_advection.f, restated)
 // ------------------------------------------------------------------------------------
 struct Advection1D {
-    static constexpr int MEQN = 1, MWAVES = 1, NCELL = 1;
+    static constexpr int MEQN = 1, MWAVES = 1, NCELL = 1, NAUX = 0;
     struct Cell { double q[1]; };
     template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
     template <int IXY>
@@ -123,7 +123,7 @@ struct Advection1D {
 // 1-D acoustics (third-party rp1_acoustics.f, restated); par = rho,bulk,cc,zz
 // ------------------------------------------------------------------------------------
 struct Acoustics1D {
-    static constexpr int MEQN = 2, MWAVES = 2, NCELL = 2;
+    static constexpr int MEQN = 2, MWAVES = 2, NCELL = 2, NAUX = 0;
     struct Cell { double q[2]; };
     template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
     template <int IXY>
@@ -150,7 +150,7 @@ struct Acoustics1D {
 // q = (p, u, v); par = rho,bulk,cc,zz
 // ------------------------------------------------------------------------------------
 struct Acoustics2D {
-    static constexpr int MEQN = 3, MWAVES = 2, NCELL = 3;
+    static constexpr int MEQN = 3, MWAVES = 2, NCELL = 3, NAUX = 0;
     struct Cell { double q[3]; };
     template <int IXY> __device__ static constexpr bool nz(int /*mw*/, int m) {
         return m == 0 || m == (IXY == 1 ? 1 : 2);
@@ -186,13 +186,49 @@ struct Acoustics2D {
     }
 };
 
+// ---- 3-D acoustics with cell-wise impedance and sound speed (third-party rpn3_vc_acoustics.f, restated;
+// named by the reference's test/acoustics/3d/Makefile) --------------------------------------------------
+// q = (p, u, v, w); aux(1) = Z, aux(2) = c.  DIR = 1,2,3 selects the normal velocity q(DIR).
+struct VcAcoustics3D {
+    static constexpr int MEQN = 4, MWAVES = 2, NAUX = 2;
+    struct Cell { double q[4]; double z, c; };
+    template <int DIR> __device__ static constexpr bool nz(int /*mw*/, int m) { return m == 0 || m == DIR; }
+    template <int DIR>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &, const double *auxv) {
+        Cell c;
+        for (int m = 0; m < 4; m++) c.q[m] = q[m];
+        c.z = auxv[0];
+        c.c = auxv[1];
+        return c;
+    }
+    template <int DIR>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &,
+                                                 double (&wave)[2][4], double (&s)[2], double (&amdq)[4],
+                                                 double (&apdq)[4]) {
+        constexpr int mu = DIR;
+        const double d1 = R.q[0] - L.q[0];
+        const double d2 = R.q[mu] - L.q[mu];
+        const double zi = R.z, zim = L.z;
+        const Recip by_zz(zim + zi);
+        const double a1 = by_zz.div(-d1 + zi * d2);
+        const double a2 = by_zz.div(d1 + zim * d2);
+        for (int m = 0; m < 4; m++) { wave[0][m] = 0.0; wave[1][m] = 0.0; }
+        wave[0][0] = -a1 * zim; wave[0][mu] = a1; s[0] = -L.c;
+        wave[1][0] = a2 * zi;   wave[1][mu] = a2; s[1] = R.c;
+        for (int m = 0; m < 4; m++) {
+            amdq[m] = nz<DIR>(0, m) ? s[0] * wave[0][m] : 0.0;
+            apdq[m] = nz<DIR>(1, m) ? s[1] * wave[1][m] : 0.0;
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------
 // 2-D Euler, Roe solver with 5 waves (acoustic-, shear, entropy, acoustic+, tracer) and
 // the Harten-Hyman entropy fix: development/rp_approaches/rpn2_euler_5wave.f:87-298,
 // transverse split rpt2_euler_5wave_rec_loc.f:50-116.  par = gamma, gamma1.
 // ------------------------------------------------------------------------------------
 struct Euler5 {
-    static constexpr int MEQN = 5, MWAVES = 5, NCELL = 12;
+    static constexpr int MEQN = 5, MWAVES = 5, NCELL = 12, NAUX = 0;
     struct Cell {
         double q[5];
         double rs;      // sqrt(rho)                       rpn2:88-89

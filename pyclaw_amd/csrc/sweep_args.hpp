@@ -39,6 +39,12 @@ struct SweepArgs {
     // (they read no ghost cell), 2 = only the tiles outside the box.
     int sub;
     int box[4];
+    // 3-D dimension-split sweeps (sweep3_kernel) only: strides in doubles along the sweep / across a tile /
+    // per batch (blockIdx.y), extents with ghost cells, interior cells along the sweep, and the inclusive
+    // ranges of across / batch indices whose slices are swept (the others are copied through)
+    long s_al, s_ac, s_b;
+    int n_al, n_ac, n_b, m_al;
+    int lo_ac, hi_ac, lo_b, hi_b;
     // unsplit algorithm (step2.f) only:
     int trans;        // method(3): 0 no transverse terms, 1 increment waves, 2 + correction waves
     double dtd_t;     // dt/d of the transverse direction
@@ -79,6 +85,7 @@ namespace exact {
 int launch_sweep(const SweepLaunch &l, std::string &err);
 // x-pass tiles [tb_lo,tb_hi) x [ta_lo,ta_hi) that read no ghost cell; false if there are none
 bool x_interior_box(const SweepArgs &a, int box[4]);
+int launch_sweep3(const SweepLaunch &l, std::string &err);   // 3-D dim-split sweep, l.ids = direction 1..3
 int launch_slices(const SweepLaunch &l, std::string &err);   // unsplit: per-slice pieces -> scratch
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase
@@ -87,6 +94,7 @@ int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 }
 namespace fast {
 int launch_sweep(const SweepLaunch &l, std::string &err);
+int launch_sweep3(const SweepLaunch &l, std::string &err);
 int launch_slices(const SweepLaunch &l, std::string &err);
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase

@@ -116,6 +116,24 @@ class Grid(object):
                 self.gauges.append(list(gauge_ind))
                 self.gauge_files.append(open(gauge_path, 'a'))
 
+    # computational cell-centre coordinates as ndim mesh arrays (grid.py:255-291, 456-486)
+    _c_center = None
+
+    def compute_c_center(self, recompute=False):
+        if recompute or self._c_center is None:
+            if self.ndim == 1:
+                self._c_center = [self.dimensions[0].center]
+            else:
+                index = np.indices(self.ng)
+                self._c_center = [c[index[i, ...]] for i, c in enumerate(self.get_dim_attribute('center'))]
+
+    @property
+    def c_center(self):
+        self.compute_c_center()
+        return self._c_center
+
+    p_center = c_center          # identity mapping (grid.py:293: mapc2p defaults to the identity)
+
     def get_dim_attribute(self, attr):
         return [getattr(getattr(self, name), attr) for name in self._dimensions]
 

@@ -36,7 +36,11 @@ rp_acoustics_1d = RiemannSolver("acoustics_1d", 2, 1, 2, 2, ["rho", "bulk", "cc"
 rp_acoustics_2d = RiemannSolver("acoustics_2d", 10, 2, 3, 2, ["rho", "bulk", "cc", "zz"], True)
 rp_euler_5wave_2d = RiemannSolver("euler_5wave_2d", 11, 2, 5, 5, ["gamma", "gamma1"], True)
 
-_ALL = [rp_advection_1d, rp_acoustics_1d, rp_acoustics_2d, rp_euler_5wave_2d]
+# 3-D acoustics, impedance and sound speed per cell in aux(1), aux(2) (test/acoustics/3d/Makefile:
+# rpn3_vc_acoustics.f; the transverse rpt3/rptt3 of the unsplit algorithm are not built: dim_split only)
+rp_vc_acoustics_3d = RiemannSolver("vc_acoustics_3d", 20, 3, 4, 2, [])
+
+_ALL = [rp_advection_1d, rp_acoustics_1d, rp_acoustics_2d, rp_euler_5wave_2d, rp_vc_acoustics_3d]
 BY_NAME = dict((r.name, r) for r in _ALL)
 
 
