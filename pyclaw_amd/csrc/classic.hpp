@@ -704,73 +704,119 @@ __global__ __launch_bounds__(256) void combine_kernel(CombineArgs c) {
 // as [al][ac] with pitch 17 (coalesced 128-byte row segments in, conflict-free column reads out).
 // Slices are swept only for transverse indices 0..m+1 (one ghost layer, step3ds.f:110-111,176-177,245-246);
 // every other cell is copied through, so the output array is complete.
-// First version: correct and coalesced, not yet tuned like the 2-D kernel (unaligned row pieces in DIR 1).
 template <class RP, int DIR>
 __global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac, int ntiles_al) {
     constexpr int MEQN = RP::MEQN, NAUX = RP::NAUX, NP = MEQN + NAUX;
-    constexpr int AC = 16, PITCH = DIR == 1 ? WAVE : AC + 1;
-    constexpr int PLANE = DIR == 1 ? AC * WAVE : WAVE * (AC + 1);
+    // DIR 1 (along i): 4 rows x 244 cells, each wavefront walks the 4 strips of its row: 240 updated cells =
+    // 15 whole lines per row, like the 2-D x pass.  DIR 2, 3: 64 cells along x 16 columns, one strip per column.
+    constexpr int NSTRIP = DIR == 1 ? 4 : 1;
+    constexpr int ADV = NSTRIP * STRIP, ALONG = ADV + 2 * HALO;
+    constexpr int AC = DIR == 1 ? 4 : 16;
+    constexpr int PLANE = DIR == 1 ? AC * ALONG : ALONG * (AC + 1);
+    constexpr int UNITS = NSTRIP * AC / 4;
     __shared__ double tile[NP * PLANE];
-    auto at = [](int m, int al, int ac) { return m * PLANE + (DIR == 1 ? ac * PITCH + al : al * PITCH + ac); };
+    auto at = [](int m, int al, int ac) { return m * PLANE + (DIR == 1 ? ac * ALONG + al : al * (AC + 1) + ac); };
 
     const int tb = DIR == 1 ? blockIdx.x / ntiles_al : blockIdx.x % ntiles_ac;
     const int ta = DIR == 1 ? blockIdx.x % ntiles_al : blockIdx.x / ntiles_ac;
     const int bt = blockIdx.y;
-    const int b0 = tb * AC, a0 = a.mbc - HALO + ta * STRIP;
+    // across = i (DIR 2, 3): column tiles start LEAD cells before cell 0 so that every 16-cell row segment
+    // is one 128-byte line (the array base is shifted so that cell mbc starts a line, pclaw.hip)
+    const int b0 = DIR == 1 ? tb * AC : tb * AC - (LINE - a.mbc);
+    const int a0 = a.mbc - HALO + ta * ADV;
     const long base = (long)bt * a.s_b;
 
     // cooperative load: memory-contiguous index fastest across the threads
-    const int l_al = DIR == 1 ? threadIdx.x % WAVE : threadIdx.x / AC;
-    const int l_ac = DIR == 1 ? threadIdx.x / WAVE : threadIdx.x % AC;
-    constexpr int STEP_AL = DIR == 1 ? 0 : 256 / AC, STEP_AC = DIR == 1 ? 256 / WAVE : 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
+    auto load = [&](int al, int ac) {
         int ga = a0 + al, gb = b0 + ac;
         ga = ga < a.n_al ? ga : a.n_al - 1;
-        gb = gb < a.n_ac ? gb : a.n_ac - 1;
+        gb = gb < 0 ? 0 : (gb < a.n_ac ? gb : a.n_ac - 1);
         const long g = base + (long)ga * a.s_al + (long)gb * a.s_ac;
 #pragma unroll
         for (int m = 0; m < MEQN; m++) tile[at(m, al, ac)] = a.qin[m * a.plane + g];
 #pragma unroll
         for (int m = 0; m < NAUX; m++) tile[at(MEQN + m, al, ac)] = a.aux[m * a.plane + g];
+    };
+    if (DIR == 1) {
+        if ((int)threadIdx.x < ALONG) {
+#pragma unroll
+            for (int ac = 0; ac < AC; ac++) load(threadIdx.x, ac);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ALONG; k += 256 / AC) load(k + threadIdx.x / AC, threadIdx.x % AC);
     }
     __syncthreads();
 
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    const int ca = a0 + lane;
-    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.m_al) && lane >= HALO && lane < WAVE - HALO;
-    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
     const bool batch_live = bt >= a.lo_b && bt <= a.hi_b;
+    auto unit_ac = [&](int u) { return DIR == 1 ? wv : wv + 4 * u; };
+    auto unit_al = [&](int u) { return (DIR == 1 ? u * STRIP : 0) + lane; };
+    auto unit_live = [&](int u) {  // wave-uniform: the slice is swept and the strip reaches interior cells
+        const int gb = b0 + unit_ac(u);
+        return u < UNITS && batch_live && gb >= a.lo_ac && gb <= a.hi_ac &&
+               a0 + (DIR == 1 ? u * STRIP : 0) + HALO < a.mbc + a.m_al;
+    };
     double cflmax = 0.0;
-    for (int ac = wv; ac < AC; ac += 256 / WAVE) {
-        const int gb = b0 + ac;
-        if (!batch_live || gb < a.lo_ac || gb > a.hi_ac) continue;  // wave-uniform: slice not swept
-        double q[MEQN], qn[MEQN], auxv[NAUX > 0 ? NAUX : 1];
+    // strips of one row (DIR 1) overlap by 2*HALO cells in the tile and results go back in place: the next
+    // strip's cells are read before this strip's results are written (LDS keeps a wavefront's order)
+    double q[MEQN], auxv[NAUX > 0 ? NAUX : 1];
+    bool have = false;
+    auto fetch = [&](int u) {
 #pragma unroll
-        for (int m = 0; m < MEQN; m++) q[m] = tile[at(m, lane, ac)];
+        for (int m = 0; m < MEQN; m++) q[m] = tile[at(m, unit_al(u), unit_ac(u))];
 #pragma unroll
-        for (int m = 0; m < NAUX; m++) auxv[m] = tile[at(MEQN + m, lane, ac)];
+        for (int m = 0; m < NAUX; m++) auxv[m] = tile[at(MEQN + m, unit_al(u), unit_ac(u))];
+    };
+#pragma unroll
+    for (int u = 0; u < UNITS; u++) {
+        if (!unit_live(u)) { have = false; continue; }
+        const int al = unit_al(u), ac = unit_ac(u);
+        const int ca = a0 + al;
+        const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.m_al) && lane >= HALO && lane < WAVE - HALO;
+        const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
+        if (!have) fetch(u);
+        double qn[MEQN];
         lane_core<RP, DIR, false, false, false, false, true>(q, a.dtd, 1.0, cfl_ok, a, qn, cflmax, nullptr, nullptr,
                                                              nullptr, auxv);
+        have = unit_live(u + 1);
+        if (have) fetch(u + 1);  // issued ahead of the writes below
         if (owned) {
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) tile[at(m, lane, ac)] = qn[m];
+            for (int m = 0; m < MEQN; m++) tile[at(m, al, ac)] = qn[m];
         }
     }
     __syncthreads();
 
     // cooperative store: cells this tile owns along the sweep + the ghost cells at the ends of the sweep
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
+    auto put = [&](int al, int ac) {
         const int ga = a0 + al, gb = b0 + ac;
-        if (ga >= a.n_al || gb >= a.n_ac) continue;
-        const bool inner = (ga >= a.mbc) && (ga < a.mbc + a.m_al);
-        if (inner && (al < HALO || al >= WAVE - HALO)) continue;  // the neighbouring tile's cells
-        const long g = base + (long)ga * a.s_al + (long)gb * a.s_ac;
+        if (ga < a.n_al && gb >= 0 && gb < a.n_ac) {
+            const long g = base + (long)ga * a.s_al + (long)gb * a.s_ac;
 #pragma unroll
-        for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[at(m, al, ac)];
+            for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[at(m, al, ac)];
+        }
+    };
+    if (DIR == 1) {
+        const int t = threadIdx.x;
+        if (t < ADV) {  // cells a0+2 .. a0+241: 15 whole lines per row
+#pragma unroll
+            for (int ac = 0; ac < AC; ac++) put(HALO + t, ac);
+        } else if (t < ADV + 2 * HALO) {  // the tile's own halo cells, only where they are ghost cells
+            const int k = t - ADV;
+            const int al = k < HALO ? k : ALONG - 2 * HALO + k;
+            const int ga = a0 + al;
+            if (ga < a.mbc || ga >= a.mbc + a.m_al)
+                for (int ac = 0; ac < AC; ac++) put(al, ac);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ALONG; k += 256 / AC) {
+            const int al = k + threadIdx.x / AC;
+            const int ga = a0 + al;
+            const bool inner = (ga >= a.mbc) && (ga < a.mbc + a.m_al);
+            if (inner ? (al >= HALO && al < ALONG - HALO) : true) put(al, threadIdx.x % AC);
+        }
     }
     cfl_publish(a.cfl, cflmax);
 }
