@@ -111,6 +111,39 @@ def cpu_baseline(nx, ny, max_seconds=30.0):
                       % (nsteps, nx, sy, el)}
 
 
+def timed_run(claw, steps, warmup):
+    """W warmup steps, then exactly K accepted steps between barrier + device sync on both sides.
+    Returns (max-over-ranks seconds, per-kernel ms sums, launch counts, result finite)."""
+    import ctypes
+    from pyclaw_amd import parallel, _lib
+    solver, solution = claw.solver, claw.solution
+    solver.setup(solution)
+    solver.dt = solver.dt_initial
+    L = _lib.lib()
+    h = solver._h
+    solver.begin_resident(solution)
+    for _ in range(warmup):
+        solver.evolve_to_time(solution)
+    _lib.check(L.pcl_kernel_timing(h, 1))
+    parallel.barrier()
+    _lib.check(L.pcl_sync(h))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.evolve_to_time(solution)
+    _lib.check(L.pcl_sync(h))
+    parallel.barrier()
+    t1 = time.perf_counter()
+    elapsed = parallel.allreduce_max_host(t1 - t0)
+    ms = np.zeros(2)
+    nl = np.zeros(2, dtype=np.int64)
+    _lib.check(L.pcl_kernel_timing_read(h, _lib.d(ms), nl.ctypes.data_as(ctypes.POINTER(ctypes.c_long))))
+    _lib.check(L.pcl_kernel_timing(h, 0))
+    solver.end_resident(solution)
+    finite = bool(np.isfinite(solution.state.q).all())
+    solver.teardown()
+    return elapsed, ms, nl, finite
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,38 +180,7 @@ def main():
         dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
         nxg, nyg = args.nx * dims[0], args.ny * dims[1]
         claw = build(nxg, nyg, args.math, args.unsplit)
-    solver, solution = claw.solver, claw.solution
-    solver.setup(solution)
-    solver.dt = solver.dt_initial
-    L = _lib.lib()
-    h = solver._h
-
-    solver.begin_resident(solution)
-    for _ in range(args.warmup):
-        solver.evolve_to_time(solution)
-
-    # ---- timed region: exactly K accepted steps --------------------------------------
-    _lib.check(L.pcl_kernel_timing(h, 1))
-    parallel.barrier()
-    _lib.check(L.pcl_sync(h))
-    nrej0 = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solver.evolve_to_time(solution)
-    _lib.check(L.pcl_sync(h))
-    parallel.barrier()
-    t1 = time.perf_counter()
-    elapsed = parallel.allreduce_max_host(t1 - t0)
-
-    ms = np.zeros(2)
-    nl = np.zeros(2, dtype=np.int64)
-    import ctypes
-    _lib.check(L.pcl_kernel_timing_read(h, _lib.d(ms), nl.ctypes.data_as(ctypes.POINTER(ctypes.c_long))))
-    _lib.check(L.pcl_kernel_timing(h, 0))
-    solver.end_resident(solution)
-    q = solution.state.q
-    finite = bool(np.isfinite(q).all())
-    solver.teardown()
+    elapsed, ms, nl, finite = timed_run(claw, args.steps, args.warmup)
 
     cells_total = float(nxg) * float(nyg) * (float(args.nx) if args.ndim == 3 else 1.0)
     value = cells_total * args.steps / elapsed / 1e6
@@ -215,6 +217,15 @@ def main():
                          "avg_ms": {names[0]: avg[0], names[1]: avg[1]},
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
+        if size == 1 and args.ndim == 2 and not args.unsplit and args.math == "exact":
+            # the same K steps in the second arithmetic mode (FMA contraction + reciprocal-multiply division;
+            # tests/test_gpu_apps.py holds it to the north-star tolerance rtol 1e-12 on the reference goldens)
+            el2, ms2, nl2, fin2 = timed_run(build(nxg, nyg, "fast", False), args.steps, args.warmup)
+            avg2 = [ms2[k] / max(1, nl2[k]) for k in range(2)]
+            out["fast_math"] = {"value": cells_total * args.steps / el2 / 1e6, "unit": "Mcell*steps/s",
+                                "ms_per_step": el2 / args.steps * 1e3, "parity": "rtol 1e-12 (not bit-identical)",
+                                "roofline_frac": bytes_launch / (max(avg2) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "avg_ms": {"x pass": avg2[0], "y pass": avg2[1]}, "result_finite": fin2}
         if args.ndim == 3:
             out["metric"] = "Mcell*steps/s, 3-D acoustics classic dim-split step (+ achieved HBM GB/s in roofline)"
         if size == 1 and not args.no_cpu_baseline and args.ndim == 2:
