@@ -215,6 +215,17 @@ int pcl_select(pcl_solver *s, int reg);
  * dt * dq/dt of the selected register (ghost cells must be filled); *cfl = max Courant number (global
  * after pcl_comm_init). */
 int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl);
+/* One Runge-Kutta stage in two kernels (2-D): dq of the selected register (pcl_sharp_dq) with the
+ * combination that consumes it fused into the last directional pass, so deltaq is never written:
+ *   op 1: D = A + dq/ca      op 2: D = ca*A + cb*(B + dq)      op 5: D = A + cb*B + cc*dq
+ * (the expressions of SharpClawSolver.step, sharpclaw.py:168-206, in the numpy evaluation order).
+ * The stage's Courant number (all-reduced over the blocks in a decomposed run) is returned in *cfl; the
+ * result becomes register D only if cfl <= cfl_max (dq() raises CFLError before the update otherwise,
+ * sharpclaw.py:228-230).  D, A, B in {PCL_REG_Q, PCL_REG_S1, PCL_REG_S2}; D's ghost cells are left
+ * unset (the next dq fills them, like the reference's apply_q_bcs on each stage). */
+int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, double ca, double cb, double cc,
+                    double cfl_max, double *cfl);
+
 /* Register arithmetic of the Runge-Kutta schemes (sharpclaw.py:168-206), evaluated in the order
  * written: op 1: D = A + B/ca   2: D = ca*A + cb*(B + C)   3: D = A/ca + cb*B
  *          4: D = ca*A - cb*B   5: D = A + cb*B + cc*C.  D, A, B, C are PCL_REG_* ids. */

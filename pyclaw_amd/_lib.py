@@ -80,6 +80,8 @@ PROTOTYPES = {
     "pcl_src": (C.c_int, [C.c_void_p, C.c_int, C.c_double, dp, C.c_int]),
     "pcl_select": (C.c_int, [C.c_void_p, C.c_int]),
     "pcl_sharp_dq": (C.c_int, [C.c_void_p, C.c_double, dp]),
+    "pcl_sharp_stage": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, dp]),
     "pcl_rk_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                             C.c_double]),
     "pcl_sync": (C.c_int, [C.c_void_p]),

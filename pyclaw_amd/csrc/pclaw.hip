@@ -7,6 +7,8 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <csignal>
+#include <execinfo.h>
 
 #include "../../include/pyclaw_amd.h"
 #include "sweep_args.hpp"
@@ -453,6 +455,15 @@ int pcl_device_count(void) {
 
 int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (!cfg || !out) return fail(PCL_EINVAL, "null argument");
+    if (getenv("PCL_TRACE_ABORT")) {   // diagnostics: C backtrace on abort()
+        signal(SIGABRT, [](int) {
+            void *bt[64];
+            const int n = backtrace(bt, 64);
+            backtrace_symbols_fd(bt, n, 2);
+            signal(SIGABRT, SIG_DFL);
+            raise(SIGABRT);
+        });
+    }
     *out = nullptr;
     if (cfg->ndim < 1 || cfg->ndim > 3) return fail(PCL_EINVAL, "ndim must be 1, 2 or 3");
     if (cfg->kind == PCL_KIND_CLASSIC && cfg->mbc != 2)
@@ -923,24 +934,58 @@ int pcl_select(pcl_solver *s, int reg) {
     return PCL_OK;
 }
 
+static int sharp_passes(pcl_solver *s, double dt, int rk_op, const double *ra, const double *rb, double *rd,
+                        double ca, double cb, double cc) {
+    std::string err;
+    for (int ids = 1; ids <= s->cfg.ndim; ids++) {
+        SweepLaunch l;
+        l.a = make_args(s, cur(s), s->sreg[PCL_REG_DQ], ids, dt);
+        if (rk_op && ids == s->cfg.ndim) {
+            l.a.rk_op = rk_op; l.a.rk_a = ra; l.a.rk_b = rb; l.a.rk_d = rd;
+            l.a.rk_ca = ca; l.a.rk_cb = cb; l.a.rk_cc = cc;
+        }
+        l.ndim = s->cfg.ndim; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave;
+        l.lim_type = s->cfg.lim_type; l.stream = s->stream;
+        pcl_solver::Timed t{};
+        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = true; hipEventRecord(t.a, s->stream); }
+        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sharp(l, err) : pcl::exact::launch_sharp(l, err);
+        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
+        if (rc) return bail(s, fail(rc, err));
+    }
+    return PCL_OK;
+}
+
 int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl) {
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_ESTATE, "SharpClaw call on a classic solver");
     if (s->sel == PCL_REG_DQ) return fail(PCL_EINVAL, "dq of the dq register");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    std::string err;
-    for (int ids = 1; ids <= s->cfg.ndim; ids++) {
-        SweepLaunch l;
-        l.a = make_args(s, cur(s), s->sreg[PCL_REG_DQ], ids, dt);
-        l.ndim = s->cfg.ndim; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave;
-        l.lim_type = s->cfg.lim_type; l.stream = s->stream;
-        pcl_solver::Timed t{};
-        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; hipEventRecord(t.a, s->stream); }
-        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sharp(l, err) : pcl::exact::launch_sharp(l, err);
-        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
-        if (rc) return bail(s, fail(rc, err));
-    }
+    if (int rc = sharp_passes(s, dt, 0, nullptr, nullptr, nullptr, 0, 0, 0)) return rc;
     return read_cfl(s, cfl);
+}
+
+int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, double ca, double cb, double cc,
+                    double cfl_max, double *cfl) {
+    if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_ESTATE, "SharpClaw call on a classic solver");
+    if (op != 1 && op != 2 && op != 5) return fail(PCL_EINVAL, "pcl_sharp_stage fuses RK ops 1, 2 and 5");
+    if (s->sel == PCL_REG_DQ || s->sel == PCL_REG_TMP) return fail(PCL_EINVAL, "stage of the dq/tmp register");
+    auto reg = [&](int r) -> double *& { return r == 0 ? s->q : s->sreg[r]; };
+    if (D < 0 || D > 2 || A < 0 || A > 2 || B < 0 || B > 2) return fail(PCL_EINVAL, "registers must be q, s1 or s2");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    // the result goes to the spare register and becomes D by a pointer swap once the stage's Courant number is
+    // known to be acceptable: D may be the register the passes read with their halo, or the state itself
+    double *spare = s->sreg[PCL_REG_TMP];
+    if (!spare || !reg(A) || !reg(B) || !reg(D) || !s->sreg[PCL_REG_DQ])
+        return fail(PCL_ESTATE, "pcl_sharp_stage: register not allocated (A=" + std::to_string(A) + " B=" + std::to_string(B) +
+                                    " D=" + std::to_string(D) + ")");
+    if (int rc = sharp_passes(s, dt, op, reg(A), reg(B), spare, ca, cb, cc)) return rc;
+    if (int rc = read_cfl(s, cfl)) return rc;
+    if (*cfl <= cfl_max) {
+        std::swap(reg(D), s->sreg[PCL_REG_TMP]);
+        s->undo_slot = nullptr;
+    }
+    return PCL_OK;
 }
 
 int pcl_rk_op(pcl_solver *s, int op, int D, int A, int B, int Cc, double ca, double cb, double cc) {

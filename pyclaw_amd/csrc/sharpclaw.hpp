@@ -214,7 +214,20 @@ __global__ __launch_bounds__(256) void sharp_kernel(SweepArgs a, int ntiles_acro
             for (int m = 0; m < MEQN; m++) {
                 const long at = m * a.plane + g;
                 const double v = tile[stile_at<IXY>(m, al, ac)];
-                a.qout[at] = IXY == 1 ? v : a.qout[at] + v;  // dq = (0 + dq1d_x) + dq1d_y
+                const double dq = IXY == 1 ? v : a.qout[at] + v;  // dq = (0 + dq1d_x) + dq1d_y
+                // last pass of a stage: the RK combination of sharpclaw.py:168-206 (same expressions as rk_kernel).
+                // Branch-free on purpose: with a scalar branch per op the ROCm 7.2 backend left the store base
+                // of the op-5 path undefined in the 1-D instantiation (memory fault at address 0).
+                double r = dq;
+                if (a.rk_op != 0) {
+                    const double av = a.rk_a[at], bv = a.rk_b[at];
+                    const double r1 = av + dq / a.rk_ca;
+                    const double r2 = a.rk_ca * av + a.rk_cb * (bv + dq);
+                    const double r5 = av + a.rk_cb * bv + a.rk_cc * dq;
+                    r = a.rk_op == 1 ? r1 : (a.rk_op == 2 ? r2 : r5);
+                }
+                double *dst = a.rk_op != 0 ? a.rk_d : a.qout;
+                dst[at] = r;
             }
         }
     }

@@ -45,6 +45,12 @@ struct SweepArgs {
     long s_al, s_ac, s_b;
     int n_al, n_ac, n_b, m_al;
     int lo_ac, hi_ac, lo_b, hi_b;
+    // SharpClaw: Runge-Kutta combination fused into the LAST directional pass (sharp_kernel store phase):
+    // rk_d = op(rk_a, rk_b, dq) per interior cell instead of writing dq (ops 1, 2, 5 of rk_kernel)
+    int rk_op;
+    const double *rk_a, *rk_b;
+    double *rk_d;
+    double rk_ca, rk_cb, rk_cc;
     // unsplit algorithm (step2.f) only:
     int trans;        // method(3): 0 no transverse terms, 1 increment waves, 2 + correction waves
     double dtd_t;     // dt/d of the transverse direction

@@ -90,39 +90,59 @@ class SharpClawSolver(Solver):
         else:
             self.start_step(self, solution)
         t, dt = state.t, self.dt
+        # st(reg, t, op, D, A, B, ...): deltaq = dq(reg, t) followed by the combination that consumes it.
+        # Without a Python dq_src both run as ONE fused device stage (pcl_sharp_stage); with one, deltaq
+        # has to visit the host and the combination is a separate register operation.
+        st = self._stage_fused if self.dq_src is None else self._stage_split
         try:
             if self.time_integrator == 'Euler':
-                self.dq(Q, t)
-                self._op(1, Q, Q, DQ, Q, ca=1.0)                      # state.q += deltaq
+                st(Q, t, 1, Q, Q, Q, ca=1.0)                          # state.q += deltaq
             elif self.time_integrator == 'SSP33':
-                self.dq(Q, t)
-                self._op(1, S1, Q, DQ, Q, ca=1.0)                     # s.q = state.q + deltaq
-                self.dq(S1, t + dt)
-                self._op(2, S1, Q, S1, DQ, ca=0.75, cb=0.25)          # 0.75*q + 0.25*(s.q+deltaq)
-                self.dq(S1, t + 0.5 * dt)
-                self._op(2, Q, Q, S1, DQ, ca=1. / 3., cb=2. / 3.)     # 1/3*q + 2/3*(s.q+deltaq)
+                st(Q, t, 1, S1, Q, Q, ca=1.0)                         # s.q = state.q + deltaq
+                st(S1, t + dt, 2, S1, Q, S1, ca=0.75, cb=0.25)        # 0.75*q + 0.25*(s.q+deltaq)
+                st(S1, t + 0.5 * dt, 2, Q, Q, S1, ca=1. / 3., cb=2. / 3.)   # 1/3*q + 2/3*(s.q+deltaq)
             elif self.time_integrator == 'SSP104':
-                self.dq(Q, t)
-                self._op(1, S1, Q, DQ, Q, ca=6.)                      # s1 = q + deltaq/6
+                st(Q, t, 1, S1, Q, Q, ca=6.)                          # s1 = q + deltaq/6
                 s1t = t + dt / 6.
                 for i in range(4):
-                    self.dq(S1, s1t)
-                    self._op(1, S1, S1, DQ, Q, ca=6.)
+                    st(S1, s1t, 1, S1, S1, Q, ca=6.)
                     s1t = s1t + dt / 6.
                 self._op(3, S2, Q, S1, Q, ca=25., cb=9. / 25)         # s2 = q/25 + 9/25*s1
                 self._op(4, S1, S2, S1, Q, ca=15., cb=5.)             # s1 = 15*s2 - 5*s1
                 s1t = t + dt / 3.
                 for i in range(4):
-                    self.dq(S1, s1t)
-                    self._op(1, S1, S1, DQ, Q, ca=6.)
+                    st(S1, s1t, 1, S1, S1, Q, ca=6.)
                     s1t = s1t + dt / 6.
-                self.dq(S1, s1t)
-                self._op(5, Q, S2, S1, DQ, cb=0.6, cc=0.1)            # q = s2 + 0.6*s1 + 0.1*deltaq
+                st(S1, s1t, 5, Q, S2, S1, cb=0.6, cc=0.1)             # q = s2 + 0.6*s1 + 0.1*deltaq
             else:
                 raise Exception('Unrecognized time integrator')
             self._host_stale = True
         except CFLError:
             return False
+
+    def _stage_split(self, reg, t, op, D, A, B, ca=0.0, cb=0.0, cc=0.0):
+        self.dq(reg, t)
+        if op == 1:
+            self._op(1, D, A, DQ, Q, ca=ca)                           # A + deltaq/ca
+        else:
+            self._op(op, D, A, B, DQ, ca=ca, cb=cb, cc=cc)
+
+    def _stage_fused(self, reg, t, op, D, A, B, ca=0.0, cb=0.0, cc=0.0):
+        """apply_q_bcs(stage) + flux1/flux2 + the RK combination on the device (sharpclaw.py:168-237)."""
+        L = _lib.lib()
+        stg = self._stage
+        stg.t = t
+        _lib.check(L.pcl_select(self._h, reg))
+        try:
+            self.apply_q_bcs(stg)
+            cfl = ctypes.c_double(0.0)
+            _lib.check(L.pcl_sharp_stage(self._h, self.dt, op, D, A, B, ca, cb, cc, float(self.cfl_max),
+                                         ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+        finally:
+            _lib.check(L.pcl_select(self._h, Q))
+        self.cfl.update_global_max(cfl.value)
+        if self.cfl.get_cached_max() > self.cfl_max:
+            raise CFLError('cfl_max exceeded')
 
     def set_mthlim(self):
         self.mthlim = self.limiters
