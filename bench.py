@@ -45,6 +45,20 @@ def build(nx_global, ny_global, math, unsplit=False):
     return claw
 
 
+def dense_state(claw, seed=0):
+    """Overwrite the initial condition with the smooth random Euler state of SURVEY 8d: waves of every
+    family at every interface, nothing for the kernels' jump-free / absent-family shortcuts to skip."""
+    rng = np.random.default_rng(seed)
+    q = claw.solution.state.q
+    shape = q.shape[1:]
+    q[0] = 1.0 + 0.1 * rng.random(shape)
+    q[1] = 0.1 * rng.random(shape)
+    q[2] = 0.05 * rng.random(shape)
+    q[3] = 2.5 + 0.1 * rng.random(shape)
+    q[4] = rng.random(shape)
+    return claw
+
+
 def build3d(n, math):
     """3-D synthetic workload: the reference's 3-D acoustics app (test/acoustics/3d/acoustics.py, 'hom' set-up:
     dim-split, periodic) on an n^3 grid with a two-material aux field."""
@@ -154,6 +168,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=["exact", "fast"], default="exact")
     ap.add_argument("--unsplit", action="store_true", help="unsplit algorithm with order_trans=2 (not the headline)")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time the fast arithmetic mode and a dense random state (fast_math, dense_state objects)")
     ap.add_argument("--ndim", type=int, default=2, choices=[2, 3],
                     help="3: 3-D dim-split acoustics on an nx^3 grid (single GPU; not the headline)")
     args = ap.parse_args()
@@ -217,7 +233,13 @@ def main():
                          "avg_ms": {names[0]: avg[0], names[1]: avg[1]},
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
-        if size == 1 and args.ndim == 2 and not args.unsplit and args.math == "exact":
+        if args.ndim == 2 and not args.unsplit:
+            out["config"]["state_note"] = (
+                "shock-bubble initial condition (BASELINE configs[2]): mostly undisturbed gas; wavefronts without a "
+                "jump take an exact shortcut and absent wave families skip the limiter (bit-identical results). "
+                "On a dense random state the same kernels take 0.47 ms per pass: `bench.py --extras` "
+                "(dense_state), profiles/r01_final_bench_extras.json, DESIGN.md 4.1")
+        if args.extras and size == 1 and args.ndim == 2 and not args.unsplit and args.math == "exact":
             # the same K steps in the second arithmetic mode (FMA contraction + reciprocal-multiply division;
             # tests/test_gpu_apps.py holds it to the north-star tolerance rtol 1e-12 on the reference goldens)
             el2, ms2, nl2, fin2 = timed_run(build(nxg, nyg, "fast", False), args.steps, args.warmup)
@@ -226,6 +248,15 @@ def main():
                                 "ms_per_step": el2 / args.steps * 1e3, "parity": "rtol 1e-12 (not bit-identical)",
                                 "roofline_frac": bytes_launch / (max(avg2) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "avg_ms": {"x pass": avg2[0], "y pass": avg2[1]}, "result_finite": fin2}
+            # and on a state with waves everywhere (no undisturbed gas): what the kernels do when no
+            # wavefront can take the jump-free shortcut and no wave family is absent
+            el3, ms3, nl3, fin3 = timed_run(dense_state(build(nxg, nyg, "exact", False)), args.steps, args.warmup)
+            avg3 = [ms3[k] / max(1, nl3[k]) for k in range(2)]
+            out["dense_state"] = {"value": cells_total * args.steps / el3 / 1e6, "unit": "Mcell*steps/s",
+                                  "ms_per_step": el3 / args.steps * 1e3, "math": "exact",
+                                  "state": "rho=1+.1U, mx=.1U, my=.05U, E=2.5+.1U, tracer=U (U uniform random per cell)",
+                                  "roofline_frac": bytes_launch / (max(avg3) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "avg_ms": {"x pass": avg3[0], "y pass": avg3[1]}, "result_finite": fin3}
         if args.ndim == 3:
             out["metric"] = "Mcell*steps/s, 3-D acoustics classic dim-split step (+ achieved HBM GB/s in roofline)"
         if size == 1 and not args.no_cpu_baseline and args.ndim == 2:

@@ -124,6 +124,40 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
     const double dtdx_l = CAPA ? from_left(dtdx_c) : dtdx_c;
 
     double wave[MWAVES][MEQN], s[MWAVES], amdq[MEQN], apdq[MEQN];
+
+    // A wavefront without a single jump (every lane's cell equals its left neighbour: undisturbed gas,
+    // the inside of the bubble, a constant post-shock state): all waves, fluctuations and correction
+    // fluxes are zero and the update is the identity, whatever the limiter -- the reference computes exactly
+    // that (q + 0).  Only the wave speeds are needed, for the Courant number (flux2.f:109-117); they come
+    // from the same Roe average the full solve uses.  Wave-uniform branch; a non-finite speed (unphysical
+    // state) takes the full path.  PCL_TUNE_ABLATE bit 4 switches the shortcut off (tools/kbench.py).
+    if constexpr (!TRANS) {
+        const bool lane0 = (threadIdx.x & (WAVE - 1)) == 0;   // lane 0 has no left cell
+        // first component first: where the state varies at all, one compare per lane settles it
+        bool same = !(a.ablate & 16) && __all(lane0 || cL.q[0] == cR.q[0]);
+        if (same) {
+            bool rest = true;
+#pragma unroll
+            for (int m = 1; m < MEQN; m++) rest = rest && (cL.q[m] == cR.q[m]);
+            same = __all(lane0 || rest);
+        }
+        if (same) {
+            RP::template speeds<IXY>(cL, cR, a.par, s);
+            bool finite = true;
+#pragma unroll
+            for (int mw = 0; mw < MWAVES; mw++) finite = finite && (s[mw] - s[mw] == 0.0);
+            if (__all(finite || (threadIdx.x & (WAVE - 1)) == 0)) {
+                if (cfl_ok && !(a.ablate & 8)) {
+#pragma unroll
+                    for (int mw = 0; mw < MWAVES; mw++)
+                        cflmax = dmax(dmax(cflmax, dtdx_c * s[mw]), -dtdx_l * s[mw]);
+                }
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) qn[m] = q[m];
+                return;
+            }
+        }
+    }
     RP::template solve<IXY>(cL, cR, a.par, wave, s, amdq, apdq);
 
     // Courant number, flux2.f:109-117

@@ -117,6 +117,11 @@ struct Advection1D {
         amdq[0] = dmin(u, 0.0) * wave[0][0];
         apdq[0] = dmax(u, 0.0) * wave[0][0];
     }
+    // wave speeds alone (what solve() would return in s), for wavefronts without any jump (classic.hpp)
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &, const Cell &, const RpParams &p, double (&s)[1]) {
+        s[0] = p.v[0];
+    }
 };
 
 // ------------------------------------------------------------------------------------
@@ -142,6 +147,10 @@ struct Acoustics1D {
         wave[0][0] = -a1 * zz; wave[0][1] = a1; s[0] = -cc;
         wave[1][0] = a2 * zz;  wave[1][1] = a2; s[1] = cc;
         for (int m = 0; m < 2; m++) { amdq[m] = s[0] * wave[0][m]; apdq[m] = s[1] * wave[1][m]; }
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &, const Cell &, const RpParams &p, double (&s)[2]) {
+        s[0] = -p.v[2]; s[1] = p.v[2];
     }
 };
 
@@ -172,6 +181,10 @@ struct Acoustics2D {
         wave[0][0] = -a1 * zz; wave[0][mu] = a1; wave[0][mv] = 0.0; s[0] = -cc;
         wave[1][0] = a2 * zz;  wave[1][mu] = a2; wave[1][mv] = 0.0; s[1] = cc;
         for (int m = 0; m < 3; m++) { amdq[m] = s[0] * wave[0][m]; apdq[m] = s[1] * wave[1][m]; }
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &, const Cell &, const RpParams &p, double (&s)[2]) {
+        s[0] = -p.v[2]; s[1] = p.v[2];
     }
     template <int IXY>
     __device__ static __forceinline__ void transverse(const Cell &, const Cell &, const RpParams &p,
@@ -219,6 +232,10 @@ struct VcAcoustics3D {
             amdq[m] = nz<DIR>(0, m) ? s[0] * wave[0][m] : 0.0;
             apdq[m] = nz<DIR>(1, m) ? s[1] * wave[1][m] : 0.0;
         }
+    }
+    template <int DIR>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &, double (&s)[2]) {
+        s[0] = -L.c; s[1] = R.c;
     }
 };
 
@@ -273,6 +290,11 @@ struct Euler5 {
         r.g1a2 = fdiv(gamma1, a2);
         r.euv = r.enth - r.u2v2;
         return r;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &par, double (&s)[5]) {
+        const Roe r = roe(L, R, par.v[1]);
+        s[0] = r.u - r.a; s[1] = r.u; s[2] = r.u; s[3] = r.u + r.a; s[4] = r.u;
     }
     template <int IXY>
     __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &par,

@@ -232,3 +232,48 @@ def test_step2_unsplit_capa_bitexact(coracle):
     inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
     assert np.array_equal(out[inner], ref[inner]), np.abs(out[inner] - ref[inner]).max()
     assert cfl.value == cfl_ref
+
+
+@pytest.mark.parametrize("ids", [1, 2])
+@pytest.mark.parametrize("case", ["patches", "uniform", "unphysical"])
+def test_jump_free_wavefronts_bitexact(coracle, ids, case):
+    """Wavefronts whose cells are all equal take a shortcut (only the wave speeds are computed, the update is
+    the identity): piecewise-constant states -- patches of constant gas next to random ones, a fully uniform
+    state (the Courant number must still come out identical), and a constant UNPHYSICAL state (negative
+    pressure => NaN speeds => the shortcut must stand back: the patch comes out NaN like the reference's.
+    NaN-for-NaN equality with the oracle is not asserted there: max/min of a NaN differ between v_max_f64
+    and Fortran's dmax1)."""
+    L = _lib()
+    rng = np.random.default_rng(17 + ids)
+    mx, my, mbc = 300, 140, 2
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    q0 = euler_transonic_state(rng, shape)
+    const = np.array([1.3, 0.4, -0.2, 2.9, 0.5])
+    if case == "patches":
+        q0[:, 70:250, 20:110] = const[:, None, None]              # a block of constant gas, moving
+        q0[:, :40, :] = np.array([0.1, 0.0, 0.0, 2.5, 1.0])[:, None, None]   # a still strip incl. ghost cells
+    elif case == "uniform":
+        q0[...] = const[:, None, None]
+    else:
+        q0[:, 100:260, 30:100] = np.array([1.0, 0.5, 0.5, 0.1, 0.0])[:, None, None]   # p < 0
+    par = np.array([1.4, 0.4])
+    mth = np.array([4, 4, 4, 4, 2], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 0.7 / my, 0.02 / max(mx, my)
+    ref = q0.copy("F")
+    with np.errstate(all="ignore"):
+        _, cfl_ref = coracle.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), ref, None,
+                                     dx, dy, dt, METHOD_DS, mth, ids)
+    out = q0.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 0, mbc, mx, my, L.d(q0), L.d(out),
+                                None, dx, dy, dt, L.i(METHOD_DS), L.i(mth), C.cast(C.byref(cfl), L.dp), ids))
+    if case == "unphysical":
+        inner = (slice(0, 4), slice(110, 250), slice(40, 90))    # (the tracer's known-zero wave entries are
+        assert np.isnan(ref[inner]).all() and np.isnan(out[inner]).all()   # skipped on the device: 0, not NaN*0)
+        ok = ~(np.isnan(ref) | np.isnan(out))
+        assert np.array_equal(out[ok], ref[ok])
+    else:
+        assert np.array_equal(out, ref), "max diff %g" % np.abs(out - ref).max()
+        assert cfl.value == cfl_ref and cfl.value > 0
+    if case == "uniform":
+        assert np.array_equal(out, q0)
