@@ -131,7 +131,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
     // that (q + 0).  Only the wave speeds are needed, for the Courant number (flux2.f:109-117); they come
     // from the same Roe average the full solve uses.  Wave-uniform branch; a non-finite speed (unphysical
     // state) takes the full path.  PCL_TUNE_ABLATE bit 4 switches the shortcut off (tools/kbench.py).
-    if constexpr (!TRANS) {
+    {
         const bool lane0 = (threadIdx.x & (WAVE - 1)) == 0;   // lane 0 has no left cell
         // first component first: where the state varies at all, one compare per lane settles it
         bool same = !(a.ablate & 16) && __all(lane0 || cL.q[0] == cR.q[0]);
@@ -153,7 +153,10 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                         cflmax = dmax(dmax(cflmax, dtdx_c * s[mw]), -dtdx_l * s[mw]);
                 }
 #pragma unroll
-                for (int m = 0; m < MEQN; m++) qn[m] = q[m];
+                for (int m = 0; m < MEQN; m++) {
+                    if constexpr (TRANS) { qn[m] = 0.0; df[m] = 0.0; g1[m] = 0.0; g2[m] = 0.0; }  // the slice's pieces
+                    else qn[m] = q[m];
+                }
                 return;
             }
         }
