@@ -59,6 +59,35 @@ def dense_state(claw, seed=0):
     return claw
 
 
+def build_sharp(nx, ny, math):
+    """SharpClaw (WENO5 + SSP104, 10 right-hand sides per step) on the shock-bubble problem."""
+    import pyclaw_amd as pyclaw
+    from apps import problems
+    x = pyclaw.Dimension('x', 0.0, 2.0, nx)
+    y = pyclaw.Dimension('y', 0.0, 0.5, ny)
+    state = pyclaw.State(pyclaw.Grid([x, y]), 5, 1)
+    state.aux_global['gamma'] = problems.gamma
+    state.aux_global['gamma1'] = problems.gamma1
+    problems.sb_qinit(state)
+    problems.sb_auxinit(state)
+    solver = pyclaw.SharpClawSolver2D()
+    solver.rp = pyclaw.riemann.rp_euler_5wave_2d
+    solver.mwaves = 5
+    solver.lim_type = 2
+    solver.math = math
+    rinf, vinf, einf = problems.shock_state()
+    solver.user_bc_lower = pyclaw.ConstantStateBC([rinf, rinf * vinf, 0., einf, 0.])
+    solver.bc_lower = [pyclaw.BC.custom, pyclaw.BC.reflecting]
+    solver.bc_upper = [pyclaw.BC.outflow, pyclaw.BC.outflow]
+    solver.aux_bc_lower = [pyclaw.BC.outflow] * 2
+    solver.aux_bc_upper = [pyclaw.BC.outflow] * 2
+    solver.dt_initial = 0.4 * (2.0 / nx)
+    claw = pyclaw.Controller()
+    claw.solution = pyclaw.Solution(state)
+    claw.solver = solver
+    return claw
+
+
 def build3d(n, math):
     """3-D synthetic workload: the reference's 3-D acoustics app (test/acoustics/3d/acoustics.py, 'hom' set-up:
     dim-split, periodic) on an n^3 grid with a two-material aux field."""
@@ -170,6 +199,8 @@ def main():
     ap.add_argument("--unsplit", action="store_true", help="unsplit algorithm with order_trans=2 (not the headline)")
     ap.add_argument("--extras", action="store_true",
                     help="also time the fast arithmetic mode and a dense random state (fast_math, dense_state objects)")
+    ap.add_argument("--solver", choices=["classic", "sharpclaw"], default="classic",
+                    help="sharpclaw: WENO5 + SSP104 on the same problem (single GPU; not the headline)")
     ap.add_argument("--ndim", type=int, default=2, choices=[2, 3],
                     help="3: 3-D dim-split acoustics on an nx^3 grid (single GPU; not the headline)")
     args = ap.parse_args()
@@ -192,6 +223,12 @@ def main():
         args.ny = args.nx
         dims, nxg, nyg = [1, 1, 1], args.nx, args.nx
         claw = build3d(args.nx, args.math)
+    elif args.solver == "sharpclaw":
+        if size != 1:
+            sys.stderr.write("bench.py --solver sharpclaw runs on one GPU here\n")
+            sys.exit(2)
+        dims, nxg, nyg = [1, 1], args.nx, args.ny
+        claw = build_sharp(nxg, nyg, args.math)
     else:
         dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
         nxg, nyg = args.nx * dims[0], args.ny * dims[1]
@@ -211,6 +248,12 @@ def main():
             # per directional sweep: read q (4) + aux (2), write q (4) doubles per cell
             names = [ns + "sweep3_kernel<VcAcoustics3D, 1> (x sweep)", ns + "sweep3_kernel<VcAcoustics3D, 2|3> (y, z sweeps)"]
             bytes_launch = (4 + 2 + 4) * 8 * float(args.nx) ** 3
+        if args.solver == "sharpclaw":
+            # x pass: read the stage (5), write dq (5); y pass: read the stage, dq and the RK operand, write the result
+            names = [ns + "sharp_kernel<Euler5, 1> (x pass of one RK stage)",
+                     ns + "sharp_kernel<Euler5, 2> (y pass + fused RK combination)"]
+            per = [80.0, 160.0]
+            bytes_launch = per[dom] * float(args.nx) * float(args.ny)
         achieved = bytes_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         out = {
             "metric": "Mcell*steps/s, 2-D Euler classic dim-split step (+ achieved HBM GB/s in roofline)",
@@ -229,17 +272,23 @@ def main():
                        "steps_incl_rejected": int(nl[0]), "result_finite": finite},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.math, dom, args.nx, args.ny) if args.ndim == 2 else None,
+                         "traffic": pmc_traffic(args.math, dom, args.nx, args.ny)
+                         if (args.ndim == 2 and args.solver == "classic" and not args.unsplit) else None,
                          "avg_ms": {names[0]: avg[0], names[1]: avg[1]},
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
-        if args.ndim == 2 and not args.unsplit:
+        if args.solver == "sharpclaw":
+            out["metric"] = "Mcell*steps/s, 2-D Euler SharpClaw WENO5 + SSP104 step (10 right-hand sides per step)"
+            out["config"]["workload"] = ("apps/euler 2D shock-bubble, %dx%d cells, SharpClaw lim_type=2 (WENO5), "
+                                         "SSP104, source off" % (args.nx, args.ny))
+        if args.ndim == 2 and not args.unsplit and args.solver == "classic":
             out["config"]["state_note"] = (
                 "shock-bubble initial condition (BASELINE configs[2]): mostly undisturbed gas; wavefronts without a "
                 "jump take an exact shortcut and absent wave families skip the limiter (bit-identical results). "
                 "On a dense random state the same kernels take 0.47 ms per pass: `bench.py --extras` "
                 "(dense_state), profiles/r01_final_bench_extras.json, DESIGN.md 4.1")
-        if args.extras and size == 1 and args.ndim == 2 and not args.unsplit and args.math == "exact":
+        if args.extras and size == 1 and args.ndim == 2 and not args.unsplit and args.math == "exact" \
+                and args.solver == "classic":
             # the same K steps in the second arithmetic mode (FMA contraction + reciprocal-multiply division;
             # tests/test_gpu_apps.py holds it to the north-star tolerance rtol 1e-12 on the reference goldens)
             el2, ms2, nl2, fin2 = timed_run(build(nxg, nyg, "fast", False), args.steps, args.warmup)
@@ -259,7 +308,7 @@ def main():
                                   "avg_ms": {"x pass": avg3[0], "y pass": avg3[1]}, "result_finite": fin3}
         if args.ndim == 3:
             out["metric"] = "Mcell*steps/s, 3-D acoustics classic dim-split step (+ achieved HBM GB/s in roofline)"
-        if size == 1 and not args.no_cpu_baseline and args.ndim == 2:
+        if size == 1 and not args.no_cpu_baseline and args.ndim == 2 and args.solver == "classic":
             try:
                 out["cpu_baseline"] = cpu_baseline(args.nx, args.ny)
             except Exception as e:      # the oracle is optional infrastructure, never the product
