@@ -90,17 +90,19 @@ def build_sharp(nx, ny, math):
 
 def build3d(n, math):
     """3-D synthetic workload: the reference's 3-D acoustics app (test/acoustics/3d/acoustics.py, 'hom' set-up:
-    dim-split, periodic) on an n^3 grid with a two-material aux field."""
+    dim-split, periodic) on an n[0] x n[1] x n[2] grid with a two-material aux field."""
     import pyclaw_amd as pyclaw
     from apps import problems
-    claw = problems.acoustics3D(pyclaw, mx=n, my=n, mz=n, run=False, math=math)
+    if isinstance(n, int):
+        n = (n, n, n)
+    claw = problems.acoustics3D(pyclaw, mx=n[0], my=n[1], mz=n[2], run=False, math=math)
     st = claw.solution.state
     X, Y, Z = st.grid.c_center
     st.aux[0] = 1.0 + (X >= 0.)                     # impedance 1 | 2
     st.aux[1] = 1.0 + (X >= 0.)                     # sound speed 1 | 2
     r = np.sqrt((X + 0.5) ** 2 + Y ** 2 + Z ** 2)
     st.q[0] = (np.abs(r - 0.3) <= 0.1) * (1. + np.cos(np.pi * (r - 0.3) / 0.1))
-    claw.solver.dt_initial = 0.4 * (2.0 / n) / 2.0
+    claw.solver.dt_initial = 0.4 * (2.0 / max(n)) / 2.0
     return claw
 
 
@@ -215,14 +217,13 @@ def main():
         sys.exit(2)
 
     if args.ndim == 3:
-        if size != 1:
-            sys.stderr.write("bench.py --ndim 3 runs on one GPU (3-D decomposition is not built yet)\n")
-            sys.exit(2)
+        # weak scaling: n^3 cells per GPU, blocks cut in y and z (x-rows stay whole)
         if args.nx == 4096:
             args.nx = 512
         args.ny = args.nx
-        dims, nxg, nyg = [1, 1, 1], args.nx, args.nx
-        claw = build3d(args.nx, args.math)
+        pd = parallel.proc_grid([args.nx, args.nx], size) if size > 1 else [1, 1]
+        dims, nxg, nyg = [1] + pd, args.nx, args.nx * pd[0]
+        claw = build3d((args.nx, args.nx * pd[0], args.nx * pd[1]), args.math)
     elif args.solver == "sharpclaw":
         if size != 1:
             sys.stderr.write("bench.py --solver sharpclaw runs on one GPU here\n")
@@ -235,7 +236,7 @@ def main():
         claw = build(nxg, nyg, args.math, args.unsplit)
     elapsed, ms, nl, finite = timed_run(claw, args.steps, args.warmup)
 
-    cells_total = float(nxg) * float(nyg) * (float(args.nx) if args.ndim == 3 else 1.0)
+    cells_total = float(nxg) * float(nyg) * (float(args.nx * dims[2]) if args.ndim == 3 else 1.0)
     value = cells_total * args.steps / elapsed / 1e6
 
     if rank == 0:
@@ -266,7 +267,7 @@ def main():
                                    "apps/euler 2D shock-bubble, %dx%d cells per GPU, classic %s, "
                                    "mthlim=[4,4,4,4,2], order 2, source off"
                                    % (args.nx, args.ny, "UNSPLIT order_trans=2" if args.unsplit else "dim-split"),
-                       "global_grid": [nxg, nyg] + ([args.nx] if args.ndim == 3 else []), "proc_grid": dims, "math": ("exact (no FMA, IEEE div/sqrt; bit-identical to the reference)" if args.math == "exact"
+                       "global_grid": [nxg, nyg] + ([args.nx * dims[2]] if args.ndim == 3 else []), "proc_grid": dims, "math": ("exact (no FMA, IEEE div/sqrt; bit-identical to the reference)" if args.math == "exact"
                                 else "fast (FMA contraction, reciprocal-multiply division; rtol 1e-12 vs reference)"),
                        "launches": {names[0]: int(nl[0]), names[1]: int(nl[1])},
                        "steps_incl_rejected": int(nl[0]), "result_finite": finite},

@@ -46,8 +46,13 @@ __host__ __device__ inline HaloRegion halo_region(int d, bool send, int I, int J
 struct HaloPlan {
     int nbr[8];
     long off[8];  // offset (doubles, per component count 1) of each direction's buffer
-    long cnt[8];  // cells in each direction's strip
-    int I, J, g;
+    long cnt[8];  // doubles per component in each direction's strip (cells x elem)
+    int I, J, g;  // the decomposed index plane (with ghosts) and the ghost width
+    // 2-D blocks: the plane is (i, j), one cell per element: elem = 1, pi = 1, pj = pitch.
+    // 3-D blocks decomposed over (y, z): the plane is (j, k) and every element is a whole x-row of the
+    // array (elem = cells per row incl. ghosts, contiguous): pi = pitch, pj = pitch * J3.
+    int elem;
+    long pi, pj;
 };
 
 __global__ void halo_pack(const double *q, double *buf, HaloPlan p, int nm, long pitch, long plane,
@@ -55,13 +60,16 @@ __global__ void halo_pack(const double *q, double *buf, HaloPlan p, int nm, long
     const int d = blockIdx.y;
     if (p.nbr[d] < 0) return;
     const HaloRegion r = halo_region(d, !unpack, p.I, p.J, p.g);
-    const long ncell = (long)r.ni * r.nj;
+    const long ncell = (long)r.ni * r.nj * p.elem;
+    (void)pitch;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell * nm;
          t += (long)gridDim.x * blockDim.x) {
         const int m = (int)(t / ncell);
         const long c = t % ncell;
-        const int jj = (int)(c / r.ni), ii = (int)(c % r.ni);
-        const long g = m * plane + (long)(r.j0 + jj) * pitch + (r.i0 + ii);
+        const int e = (int)(c % p.elem);
+        const long cc = c / p.elem;
+        const int jj = (int)(cc / r.ni), ii = (int)(cc % r.ni);
+        const long g = m * plane + (long)(r.j0 + jj) * p.pj + (long)(r.i0 + ii) * p.pi + e;
         const long b = p.off[d] * nm + t;
         if (unpack) const_cast<double *>(q)[g] = buf[b];
         else buf[b] = q[g];
@@ -99,17 +107,18 @@ public:
     }
 
     int init(int nranks, int rank, const char uid[128], const int nbr[8], int I, int J, int g,
-             int nmax, hipStream_t stream, std::string &err) {
+             int nmax, hipStream_t stream, std::string &err, int elem = 1, long pi = 1, long pj = 0) {
         if (load(err)) return -1;
         destroy();
         stream_ = stream;
         plan_.I = I; plan_.J = J; plan_.g = g;
+        plan_.elem = elem; plan_.pi = pi; plan_.pj = pj;
         long off = 0;
         for (int d = 0; d < 8; d++) {
             if (nbr[d] >= nranks) { err = "neighbour rank out of range"; return -1; }
             plan_.nbr[d] = nbr[d];
             const HaloRegion r = halo_region(d, true, I, J, g);
-            plan_.cnt[d] = (long)r.ni * r.nj;
+            plan_.cnt[d] = (long)r.ni * r.nj * elem;
             plan_.off[d] = off;
             off += plan_.cnt[d];
         }

@@ -1171,12 +1171,18 @@ int pcl_comm_unique_id(char uid[128]) {
 
 int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], const int neighbors[8]) {
     if (!s || !uid || !neighbors) return fail(PCL_EINVAL, "null argument");
-    if (s->cfg.ndim != 2) return fail(PCL_EINVAL, "halo exchange is implemented for 2-D blocks");
+    if (s->cfg.ndim < 2) return fail(PCL_EINVAL, "halo exchange is implemented for 2-D blocks and 3-D blocks decomposed over (y, z)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     std::string err;
     const int nmax = s->cfg.meqn > s->cfg.maux ? s->cfg.meqn : s->cfg.maux;
-    if (s->halo.init(nranks, rank, uid, neighbors, s->I, s->J, s->cfg.mbc, nmax, s->stream, err))
-        return fail(PCL_ECOMM, err);
+    // 2-D: the (i, j) plane of cells.  3-D: blocks are cut in y and z only; the exchanged plane is (j, k) and
+    // each element is a whole row of I cells (x ghost cells included: they are refilled by the physical BCs)
+    const int rc3 = s->cfg.ndim == 3
+                        ? s->halo.init(nranks, rank, uid, neighbors, s->J, s->K, s->cfg.mbc, nmax, s->stream, err, s->I,
+                                       s->pitch, s->pitch * s->J)
+                        : s->halo.init(nranks, rank, uid, neighbors, s->I, s->J, s->cfg.mbc, nmax, s->stream, err, 1, 1,
+                                       s->pitch);
+    if (rc3) return fail(PCL_ECOMM, err);
     if (!s->hstream) {
         HIP_TRY(hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_h0, hipEventDisableTiming));

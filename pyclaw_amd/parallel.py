@@ -135,17 +135,25 @@ def block_range(n, p, c):
 
 
 class Decomposition(object):
-    """This rank's block of a px x py decomposition of a global grid."""
+    """This rank's block of a px x py decomposition of a global grid.
 
-    def __init__(self, n_global, size, rank):
+    1-D / 2-D grids are cut along all their dimensions; a 3-D grid is cut along y and z only (`axes` =
+    [1, 2]): x-rows stay whole, so the halo is again an 8-neighbour BOX stencil, now in the (y, z) plane
+    with whole rows as elements (csrc/halo.hpp)."""
+
+    def __init__(self, n_global, size, rank, axes=None):
         self.n_global = list(n_global)
         self.size = size
         self.rank = rank
-        self.dims = proc_grid(n_global, size)
+        ndim = len(self.n_global)
+        self.axes = list(axes) if axes is not None else ([1, 2] if ndim == 3 else list(range(ndim)))
+        self.dims = proc_grid([self.n_global[a] for a in self.axes], size)
         nd = len(self.dims)
-        # rank = cx + px*cy  (x fastest, like DMDA)
+        # rank = cx + px*cy  (first decomposed axis fastest, like DMDA)
         self.coords = [rank % self.dims[0]] if nd == 1 else [rank % self.dims[0], rank // self.dims[0]]
-        self.ranges = [block_range(n_global[k], self.dims[k], self.coords[k]) for k in range(nd)]
+        self.ranges = [(0, n) for n in self.n_global]
+        for k, a in enumerate(self.axes):
+            self.ranges[a] = block_range(self.n_global[a], self.dims[k], self.coords[k])
 
     def rank_of(self, coords):
         return coords[0] if len(self.dims) == 1 else coords[0] + self.dims[0] * coords[1]
@@ -158,6 +166,7 @@ class Decomposition(object):
         physical edge wrap around only if that dimension's BC is periodic.
         """
         nd = len(self.dims)
+        periodic = [periodic[a] for a in self.axes] if len(periodic) != nd else list(periodic)
         out = []
         for (ox, oy) in _OFFSETS:
             off = [ox] if nd == 1 else [ox, oy]
@@ -191,8 +200,6 @@ def decompose(grid):
     existing = getattr(grid, "_decomp", None)
     if existing is not None:
         return existing
-    if grid.ndim > 2:
-        raise NotImplementedError("multi-GPU decomposition is implemented for 1-D/2-D grids")
     dec = Decomposition(grid.n, world_size(), rank())
     for k, dim in enumerate(grid.dimensions):
         dim._set_range(*dec.ranges[k])

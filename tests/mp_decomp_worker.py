@@ -33,33 +33,35 @@ OPP = [1, 0, 3, 2, 7, 6, 5, 4]
 def region(d, send, I, J, g):
     o = np.zeros(4, dtype=np.int32)
     _lib.check(_lib.lib().pcl_halo_region(d, int(send), I, J, g, _lib.i(o)))
-    return slice(o[0], o[0] + o[2]), slice(o[1], o[1] + o[3])
+    return (slice(o[0], o[0] + o[2]), slice(o[1], o[1] + o[3]))
 
 
 def halo_exchange(qbc, nbr, g):
-    I, J = qbc.shape[1:]
+    """2-D blocks: the (i, j) plane.  3-D blocks cut in y and z: the (j, k) plane, whole x-rows as elements
+    (what csrc/halo.hpp does with elem = I)."""
+    lead = (slice(None),) * (qbc.ndim - 2)
+    I, J = qbc.shape[-2:]
     reqs, recvs = [], []
     for d in range(8):
         if nbr[d] >= 0:
-            si, sj = region(d, True, I, J, g)
-            buf = torch.from_numpy(np.ascontiguousarray(qbc[:, si, sj]))
+            buf = torch.from_numpy(np.ascontiguousarray(qbc[lead + region(d, True, I, J, g)]))
             reqs.append(dist.isend(buf, dst=int(nbr[d])))
         o = OPP[d]
         if nbr[o] >= 0:
-            fi, fj = region(o, False, I, J, g)
-            rb = torch.empty(qbc[:, fi, fj].shape, dtype=torch.float64)
+            idx = lead + region(o, False, I, J, g)
+            rb = torch.empty(qbc[idx].shape, dtype=torch.float64)
             reqs.append(dist.irecv(rb, src=int(nbr[o])))
-            recvs.append((fi, fj, rb))
+            recvs.append((idx, rb))
     for r in reqs:
         r.wait()
-    for fi, fj, rb in recvs:
-        qbc[:, fi, fj] = rb.numpy()
+    for idx, rb in recvs:
+        qbc[idx] = rb.numpy()
 
 
 def local_bcs(qbc, g, bc_lower, bc_upper, user_lower, dec, nglob):
     """solver.py:354-381 on a block: only sides on the physical boundary; a periodic side is a
     local copy only when this block spans the whole dimension."""
-    for idim in range(2):
+    for idim in range(qbc.ndim - 1):
         lo = dec.ranges[idim][0] == 0
         hi = dec.ranges[idim][1] == nglob[idim]
         whole = lo and hi
@@ -96,6 +98,111 @@ def field(meqn, I, J):
     return np.asfortranarray(1000.0 * m + i + 0.001 * j + np.sin(0.1 * i * j))
 
 
+def acoustics3d_case(nsteps):
+    """3-D dim-split acoustics, blocks cut in y and z (parallel.Decomposition axes [1, 2]): gathered result ==
+    serial result, bit for bit -- with the limiters off.  step3ds.f sweeps only the slices 0..m+1 (ONE ghost
+    layer, step3ds.f:110-111), unlike step2ds.f which sweeps every ghost row: with a limiter (reach 2) the
+    reference's own dimension-split 3-D step therefore depends on the decomposition at block faces (the second
+    ghost layer is not x-swept before the y sweep reads it).  The product keeps the reference's per-block
+    semantics; what must be, and is, invariant is the unlimited second-order scheme (reach 1)."""
+    rank, size = parallel.rank(), parallel.world_size()
+    be = O.COracle()
+    p = D.acoustics3d_problem('hom', mx=14, my=12, mz=10)
+    rng = np.random.default_rng(9)
+    p.q[...] = rng.standard_normal(p.q.shape)
+    p.aux[0] = 1.0 + rng.random(p.q.shape[1:])
+    p.aux[1] = 0.5 + rng.random(p.q.shape[1:])
+    p.bc_lower = p.aux_bc_lower = [D.PERIODIC, D.REFLECTING, D.PERIODIC]
+    p.bc_upper = p.aux_bc_upper = [D.PERIODIC, D.OUTFLOW, D.PERIODIC]
+    p.limiters = 0
+    D.setup(p)
+    g = p.mbc
+    nglob = list(p.q.shape[1:])
+    dec = parallel.Decomposition(nglob, size, rank)
+    assert dec.axes == [1, 2] and dec.ranges[0] == (0, nglob[0])
+    periodic = [p.bc_lower[k] == D.PERIODIC for k in range(3)]
+    nbr = dec.neighbors(periodic)
+    sl = tuple(slice(a, b) for a, b in dec.ranges)
+    loc = [b - a for a, b in dec.ranges]
+
+    def padded(arr, bl, bu, is_aux):
+        out = np.zeros((arr.shape[0],) + tuple(n + 2 * g for n in loc), order="F")
+        out[(slice(None),) + (slice(g, -g),) * 3] = arr[(slice(None),) + sl]
+        halo_exchange(out, nbr, g)
+        if is_aux:
+            saved = (p.bc_lower, p.bc_upper)
+        local_bcs3(out, g, bl, bu, dec, nglob, is_aux)
+        return out
+
+    def local_bcs3(qbc, g, bl, bu, dec, nglob, is_aux):
+        for idim in range(3):
+            lo = dec.ranges[idim][0] == 0
+            hi = dec.ranges[idim][1] == nglob[idim]
+            whole = lo and hi
+            v = np.rollaxis(qbc, idim + 1, 1)
+            if lo:
+                if bl[idim] == D.REFLECTING:
+                    for i in range(g):
+                        v[:, i, ...] = v[:, 2 * g - 1 - i, ...]
+                        if not is_aux:
+                            v[idim + 1, i, ...] = -v[idim + 1, 2 * g - 1 - i, ...]
+                elif bl[idim] == D.PERIODIC and whole:
+                    v[:, :g, ...] = v[:, -2 * g:-g, ...]
+            if hi:
+                if bu[idim] == D.OUTFLOW:
+                    for i in range(g):
+                        v[:, -i - 1, ...] = v[:, -g - 1, ...]
+                elif bu[idim] == D.PERIODIC and whole:
+                    v[:, -g:, ...] = v[:, g:2 * g, ...]
+
+    auxbc = padded(p.aux, p.aux_bc_lower, p.aux_bc_upper, True)
+    q = np.array(p.q[(slice(None),) + sl], order="F")
+    qbc = np.zeros((4,) + tuple(n + 2 * g for n in loc), order="F")
+    dt = 0.02
+    inner = (slice(None),) + (slice(g, -g),) * 3
+    for _ in range(nsteps):
+        qbc[inner] = q
+        halo_exchange(qbc, nbr, g)
+        local_bcs3(qbc, g, p.bc_lower, p.bc_upper, dec, nglob, False)
+        qold = qbc.copy("F")
+        cfl = 0.0
+        for idir, qo in ((1, qold), (2, qbc), (3, qbc)):
+            _, c1 = be.step3ds(p.rp, max(loc), g, loc[0], loc[1], loc[2], qo, qbc, auxbc, p.d[0], p.d[1], p.d[2],
+                               dt, p.method, p.mthlim, idir)
+            cfl = max(cfl, c1)
+        cfl = parallel.allreduce_max_host(cfl)
+        q = np.array(qbc[inner], order="F")
+        dt = dt * 0.9 / cfl
+    parts = [None] * size
+    dist.gather_object((dec.ranges, q, dt), parts if rank == 0 else None, dst=0)
+    ok = True
+    if rank == 0:
+        full = np.zeros_like(p.q)
+        for (rg, blk, dtk) in parts:
+            full[(slice(None),) + tuple(slice(a, b) for a, b in rg)] = blk
+            assert dtk == dt
+        sq = np.array(p.q, order="F")
+        sqbc = np.zeros((4,) + tuple(n + 2 * g for n in nglob), order="F")
+        sdt = 0.02
+        for _ in range(nsteps):
+            sqbc[inner] = sq
+            D.fill_ghosts(sqbc, g, p.bc_lower, p.bc_upper)
+            sold = sqbc.copy("F")
+            scfl = 0.0
+            for idir, qo in ((1, sold), (2, sqbc), (3, sqbc)):
+                _, c1 = be.step3ds(p.rp, max(nglob), g, nglob[0], nglob[1], nglob[2], qo, sqbc, p.auxbc, p.d[0],
+                                   p.d[1], p.d[2], sdt, p.method, p.mthlim, idir)
+                scfl = max(scfl, c1)
+            sq = np.array(sqbc[inner], order="F")
+            sdt = sdt * 0.9 / scfl
+        ok = bool(np.array_equal(full, sq)) and sdt == dt
+        print("RESULT case=acoustics3d size=%d dims=%s equal=%s maxdiff=%g" % (size, dec.dims, ok,
+                                                                               np.abs(full - sq).max()))
+    parallel.barrier()
+    parallel.shutdown()
+    sys.exit(0 if ok else 1)
+
+
 def checkpoint_case(outdir):
     """every rank writes its block of a 37 x 29 state as a 'block' checkpoint, then reads the frame back
     (same decomposition) through Solution(frame, format='block')"""
@@ -127,6 +234,8 @@ def main():
     rank, size = parallel.rank(), parallel.world_size()
     if case.startswith("checkpoint:"):
         checkpoint_case(case.split(":", 1)[1])
+    if case == "acoustics3d":
+        acoustics3d_case(nsteps)
     be = O.COracle()
 
     if case == "euler":

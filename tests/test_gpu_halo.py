@@ -167,3 +167,57 @@ def test_overlapped_step_equals_periodic(mx, my, overlap, monkeypatch):
     assert res[0][1] == res[1][1] and 0 < res[0][1][0] < 1
     assert np.array_equal(res[0][0], res[1][0])
     assert not np.array_equal(res[0][0], q0)
+
+
+@pytest.mark.parametrize("shape", [(20, 9, 7), (70, 33, 18)])
+def test_3d_self_halo_equals_periodic(shape):
+    """3-D block cut in (y, z): the exchanged plane is (j, k) with whole x-rows as elements.  One rank whose 8
+    neighbours are itself == local periodic ghost fills in y and z, bit for bit, over 3 dim-split steps."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(21)
+    q0 = np.asfortranarray(rng.standard_normal((4,) + shape))
+    aux = np.empty((2,) + tuple(n + 4 for n in shape), order="F")
+    aux[0] = 1.0 + rng.random(aux.shape[1:])
+    aux[1] = 0.5 + rng.random(aux.shape[1:])
+    res = []
+    for with_comm in (False, True):
+        cfg = L.Config()
+        cfg.ndim = 3
+        for k in range(3):
+            cfg.n[k] = shape[k]
+            cfg.d[k] = 0.1
+        cfg.mbc, cfg.meqn, cfg.mwaves, cfg.rp, cfg.maux = 2, 4, 2, 20, 2
+        cfg.method[1], cfg.method[2], cfg.method[6] = 2, -1, 2
+        cfg.mthlim[0] = cfg.mthlim[1] = 4
+        h = C.c_void_p()
+        L.check(lib.pcl_create(C.byref(cfg), C.byref(h)))
+        try:
+            L.check(lib.pcl_put_aux(h, L.d(aux)))
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
+                L.check(lib.pcl_halo_exchange_aux(h))
+                bc = np.array([2, 2, -1, -1, -1, -1], dtype=np.int32)
+            else:
+                for idim in (1, 2):
+                    for side in (0, 1):
+                        L.check(lib.pcl_bc_aux(h, idim, side, 2))
+                bc = np.full(6, 2, dtype=np.int32)
+            for side in (0, 1):
+                L.check(lib.pcl_bc_aux(h, 0, side, 2))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            cfls = []
+            for _ in range(3):
+                cfl = C.c_double()
+                L.check(lib.pcl_bc_step(h, L.i(bc), L.d(np.zeros(48)), 0.01, C.cast(C.byref(cfl), L.dp)))
+                cfls.append(cfl.value)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            res.append((out, cfls))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and res[0][1][0] > 0
+    assert np.array_equal(res[0][0], res[1][0])
+    assert not np.array_equal(res[0][0], q0)

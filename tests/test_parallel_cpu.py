@@ -43,6 +43,12 @@ def test_four_ranks_equal_serial(case):
     run_workers(4, case)
 
 
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_3d_blocks_cut_in_y_and_z_equal_serial(nproc):
+    """3-D dim-split acoustics: x-rows stay whole, blocks are cut in y and z (Decomposition axes [1, 2])"""
+    run_workers(nproc, "acoustics3d", nsteps=3)
+
+
 def test_six_ranks_equal_serial():
     """the reference's own parallel tests use mpiexec -n 6 (test/util.py:64-95)"""
     run_workers(6, "acoustics_periodic")
