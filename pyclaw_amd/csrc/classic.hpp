@@ -30,24 +30,6 @@ constexpr int STRIP = WAVE - 2 * HALO;  // cells updated per wavefront strip
 // bound_ctrl:0 => the lane without a source (lane 0 / lane 63) reads 0 and no "old" value has
 // to be kept alive, so the shift is a single v_mov_b32_dpp per dword.  Those end lanes
 // never feed a stored result (only lanes 2..61 are written).
-#ifndef PCL_SHIFT_LDS
-#define PCL_SHIFT_LDS 0
-#endif
-#if PCL_SHIFT_LDS
-// ds_bpermute_b32: the shift runs on the LDS crossbar (no LDS memory), off the VALU pipe.
-__device__ __forceinline__ double from_left(double x) {  // lane l <- lane l-1
-    const int addr = (((int)threadIdx.x & (WAVE - 1)) - 1) << 2;
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double from_right(double x) {  // lane l <- lane l+1
-    const int addr = (((int)threadIdx.x & (WAVE - 1)) + 1) << 2;
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-#else
 __device__ __forceinline__ double from_left(double x) {  // lane l <- lane l-1 (lane 0 gets 0)
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
@@ -60,7 +42,6 @@ __device__ __forceinline__ double from_right(double x) {  // lane l <- lane l+1 
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-#endif
 template <class T> __device__ __forceinline__ T struct_from_left(const T &t) {
     constexpr int N = sizeof(T) / sizeof(double);
     union U { T t; double d[N]; __device__ U() {} } a, b;
