@@ -228,7 +228,9 @@ int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, doubl
 
 /* Register arithmetic of the Runge-Kutta schemes (sharpclaw.py:168-206), evaluated in the order
  * written: op 1: D = A + B/ca   2: D = ca*A + cb*(B + C)   3: D = A/ca + cb*B
- *          4: D = ca*A - cb*B   5: D = A + cb*B + cc*C.  D, A, B, C are PCL_REG_* ids. */
+ *          4: D = ca*A - cb*B   5: D = A + cb*B + cc*C
+ *          6: C = A/ca + cb*B, then D = cc*C - 5*B with D == B (ops 3 and 4 of SSP104's mid-step, sharpclaw.py:186-187,
+ *             in one pass over the registers).  D, A, B, C are PCL_REG_* ids. */
 int pcl_rk_op(pcl_solver *s, int op, int D, int A, int B, int Cc, double ca, double cb, double cc);
 
 int pcl_sync(pcl_solver *s);

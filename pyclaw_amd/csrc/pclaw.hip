@@ -991,7 +991,8 @@ int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, doubl
 int pcl_rk_op(pcl_solver *s, int op, int D, int A, int B, int Cc, double ca, double cb, double cc) {
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_ESTATE, "SharpClaw call on a classic solver");
-    if (op < 1 || op > 5) return fail(PCL_EINVAL, "unknown RK op");
+    if (op < 1 || op > 6) return fail(PCL_EINVAL, "unknown RK op");
+    if (op == 6 && (Cc == A || Cc == B || D != B)) return fail(PCL_EINVAL, "op 6 writes C and overwrites B: C must differ from A and B, D must be B");
     auto reg = [&](int r) -> double * { return r == 0 ? s->q : ((r > 0 && r < 5) ? s->sreg[r] : nullptr); };
     RkLaunch r;
     r.d = reg(D); r.a = reg(A); r.b = reg(B); r.c = reg(Cc);

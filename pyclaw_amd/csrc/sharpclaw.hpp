@@ -251,6 +251,12 @@ __global__ __launch_bounds__(256) void rk_kernel(RkOp o) {
         case 3: r = o.a[i] / o.ca + o.cb * o.b[i]; break;                   // A/c + b*B
         case 4: r = o.ca * o.a[i] - o.cb * o.b[i]; break;                   // a*A - b*B
         case 5: r = o.a[i] + o.cb * o.b[i] + o.cc * o.c[i]; break;          // A + b*B + c*C
+        case 6: {  // SSP104 mid-step pair in one pass (sharpclaw.py:186-187): C = A/ca + cb*B ; D = cc*C - 5*B
+            const double s2 = o.a[i] / o.ca + o.cb * o.b[i];
+            const_cast<double *>(o.c)[i] = s2;
+            r = o.cc * s2 - 5. * o.b[i];
+            break;
+        }
         default: r = o.a[i];
         }
         o.d[i] = r;

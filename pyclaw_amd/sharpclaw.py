@@ -107,8 +107,7 @@ class SharpClawSolver(Solver):
                 for i in range(4):
                     st(S1, s1t, 1, S1, S1, Q, ca=6.)
                     s1t = s1t + dt / 6.
-                self._op(3, S2, Q, S1, Q, ca=25., cb=9. / 25)         # s2 = q/25 + 9/25*s1
-                self._op(4, S1, S2, S1, Q, ca=15., cb=5.)             # s1 = 15*s2 - 5*s1
+                self._op(6, S1, Q, S1, S2, ca=25., cb=9. / 25, cc=15.)   # s2 = q/25 + 9/25*s1 ; s1 = 15*s2 - 5*s1
                 s1t = t + dt / 3.
                 for i in range(4):
                     st(S1, s1t, 1, S1, S1, Q, ca=6.)
