@@ -59,6 +59,8 @@ class ClawSolver(Solver):
         # no-FMA Fortran) or 'fast' (FMA + reciprocal-multiply divisions, rtol 1e-12)
         self._default_attr_values['math'] = 'exact'
         self.rp = None
+        self._cfl_out = None
+        self._cfl_ptr = None
         super(ClawSolver, self).__init__(data)
 
     # ---------------------------------------------------------------- time stepping
@@ -118,15 +120,17 @@ class ClawSolver(Solver):
         r"""One homogeneous step on the resident state (clawpack.py:299-323,510-555)."""
         import ctypes
         state = solution.states[0]
-        cfl = ctypes.c_double(0.0)
+        cfl = self._cfl_out
+        if cfl is None:            # one c_double + its pointer for the solver's lifetime
+            cfl = self._cfl_out = ctypes.c_double(0.0)
+            self._cfl_ptr = ctypes.cast(ctypes.byref(cfl), _lib.dp)
         spec = self._device_bc_spec(state)
         if spec is not None:
             # every ghost fill runs on the device: BCs + step in one library call
-            _lib.check(_lib.lib().pcl_bc_step(self._h, _lib.i(spec[0]), _lib.d(spec[1]), self.dt,
-                                              ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+            _lib.check(_lib.lib().pcl_bc_step(self._h, spec[2], spec[3], self.dt, self._cfl_ptr))
         else:
             self.apply_q_bcs(state)
-            _lib.check(_lib.lib().pcl_step_hyperbolic(self._h, self.dt, ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+            _lib.check(_lib.lib().pcl_step_hyperbolic(self._h, self.dt, self._cfl_ptr))
         self._host_stale = True
         self.cfl.update_global_max(cfl.value)
 

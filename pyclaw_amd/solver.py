@@ -236,6 +236,9 @@ class Solver(object):
                     types[k] = bc
                 else:
                     spec = None
+        if spec is not None:
+            # (types, consts, their ctypes pointers): the pointers are built once, not on every step
+            spec = (types, consts, _lib.i(types), _lib.d(consts))
         self._bc_spec_cache = (key, spec)
         return spec
 
@@ -402,7 +405,8 @@ class Solver(object):
                         solution.t += self.dt
                     else:
                         solution.t = tstart + (n + 1) * self.dt
-                    self.logger.debug("Step %i  CFL = %f   dt = %f   t = %f" % (n, cfl, self.dt, solution.t))
+                    if self.logger.isEnabledFor(logging.DEBUG):
+                        self.logger.debug("Step %i  CFL = %f   dt = %f   t = %f" % (n, cfl, self.dt, solution.t))
                     self.write_gauge_values(solution)
                     self.status['numsteps'] += 1
                     if take_one_step or solution.t >= tend:

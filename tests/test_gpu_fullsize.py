@@ -183,14 +183,14 @@ def test_c5_grid_sharpclaw_2048x1024_spot_parity(coracle):
     dq = np.zeros_like(q)
     L.check(lib.pcl_sharp_flux2(O.RP_EULER5_2D, L.d(np.array([1.4, 0.4] + [0.0] * 6)), 2, 5, 5, 1, 1, 3, nx, ny,
                                 L.d(q), L.d(dq), L.d(aux), dx, dy, dt, C.cast(C.byref(cflp), L.dp)))
-    assert np.isfinite(dq[:, 3:-3, 3:-3]).all() and cflp.value > 0
+    assert np.isfinite(dq[:, 3:-3, 3:-3]).all() and cflp.value > 0 and np.abs(dq[:, 3:-3, 3:-3]).max() > 0
     w = 32
     for (i0, j0) in list(windows(rng, (nx + 6, ny + 6), w, 8, 5)) + [(3, 3), (nx + 3 - w, ny + 3 - w)]:
         qb = np.array(q[:, i0 - 3:i0 + w + 3, j0 - 3:j0 + w + 3], order="F")
         ab = np.array(aux[:, i0 - 3:i0 + w + 3, j0 - 3:j0 + w + 3], order="F")
         ref, _ = coracle.sharp_flux2(O.RP_EULER5_2D, [1.4, 0.4], 2, 5, 1, 3, w, w, qb, ab, dx, dy, dt)
         assert np.array_equal(dq[:, i0:i0 + w, j0:j0 + w], ref[:, 3:-3, 3:-3]), (i0, j0)
-        assert ref[:, 3:-3, 3:-3].shape == (5, w, w) and np.abs(ref[:, 3:-3, 3:-3]).max() > 0
+        assert ref[:, 3:-3, 3:-3].shape == (5, w, w)
 
 
 def test_3d_acoustics_256_spot_parity_and_shift(coracle):
