@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""
+Generates tests/golden/ref_*.npz from the REFERENCE'S OWN FORTRAN (oracle/_ref: flang build of the files
+under /root/reference, oracle/Makefile) for the paths the reference ships no golden for:
+
+  ref_step2_unsplit.npz    step2.f  (unsplit, method(3) = 0, 1, 2; rpt2_euler_5wave_rec_loc.f)
+  ref_step2ds_capa.npz     step2ds.f with a capacity function (mcapa = 2), ids = 1, 2
+  ref_sharp_flux2.npz      SharpClaw flux2.f90, lim_type 2 (PyWENO weno5) and 3 (legacy weno5)
+
+Only inputs' SEEDS and the outputs are stored (inputs are regenerated from the seed by the tests).  Run in the
+build container (needs oracle/_ref, i.e. the reference tree): python tests/golden/make_ref_goldens.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import oracle as O          # noqa: E402
+
+
+def euler_state(seed, shape):
+    rng = np.random.default_rng(seed)
+    q = np.empty((5,) + shape, order="F")
+    rho = 0.5 + rng.random(shape)
+    u = 1.5 * (rng.random(shape) - 0.5)
+    v = 1.5 * (rng.random(shape) - 0.5)
+    p = 0.5 + rng.random(shape)
+    q[0] = rho
+    q[1] = rho * u
+    q[2] = rho * v
+    q[3] = p / 0.4 + 0.5 * rho * (u * u + v * v)
+    q[4] = rng.random(shape)
+    return q
+
+
+def capa_field(seed, shape):
+    return np.asfortranarray(0.5 + np.random.default_rng(seed + 1000).random((2,) + shape))
+
+
+PAR = [1.4, 0.4]
+MTH = [4, 4, 4, 4, 2]
+
+
+def main():
+    ref = O.RefEuler2D()
+    mx, my, mbc = 37, 26, 2
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    dx, dy, dt = 1.0 / mx, 0.8 / my, 0.004
+    out = {}
+    for trans in (0, 1, 2):
+        q0 = euler_state(10 + trans, shape)
+        qn = q0.copy("F")
+        method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
+        _, cfl = ref.step2(O.RP_EULER5_2D, PAR, max(mx, my), mbc, mx, my, q0.copy("F"), qn, None, dx, dy, dt, method, MTH)
+        out["q_trans%d" % trans] = qn
+        out["cfl_trans%d" % trans] = cfl
+    np.savez_compressed(os.path.join(HERE, "ref_step2_unsplit.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
+
+    out = {}
+    method = np.array([1, 2, -1, 0, 0, 2, 2], dtype=np.int32)
+    for ids in (1, 2):
+        q0 = euler_state(20 + ids, shape)
+        aux = capa_field(20 + ids, shape)
+        qn = q0.copy("F")
+        _, cfl = ref.step2ds(O.RP_EULER5_2D, PAR, max(mx, my), mbc, mx, my, q0.copy("F"), qn, aux, dx, dy, dt, method, MTH, ids)
+        out["q_ids%d" % ids] = qn
+        out["cfl_ids%d" % ids] = cfl
+    np.savez_compressed(os.path.join(HERE, "ref_step2ds_capa.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
+
+    sref = O.RefSharp2DEuler()
+    mbc = 3
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    out = {}
+    for lim in (2, 3):
+        q0 = euler_state(30 + lim, shape)
+        dq, cfl = sref.sharp_flux2(O.RP_EULER5_2D, PAR, lim, 5, 0, mbc, mx, my, q0, None, dx, dy, dt)
+        out["dq_lim%d" % lim] = dq[:, mbc:-mbc, mbc:-mbc]
+        out["cfl_lim%d" % lim] = cfl
+    np.savez_compressed(os.path.join(HERE, "ref_sharp_flux2.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
+    print("written:", [f for f in sorted(os.listdir(HERE)) if f.startswith("ref_")])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""
+Goldens generated from the REFERENCE'S OWN FORTRAN (flang build, tests/golden/make_ref_goldens.py) for the paths
+the reference ships no golden for -- unsplit step2.f (method(3) = 0/1/2), step2ds.f with a capacity function,
+SharpClaw flux2.f90 (lim_type 2 and 3).  CPU: the oracle's C restatement must reproduce them bit for bit;
+GPU (-m gpu): the HIP path, through the C ABI, must too.  Unlike tests/test_oracle_vs_ref.py these do not need
+oracle/_ref at test time.
+"""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_spec = importlib.util.spec_from_file_location("make_ref_goldens", os.path.join(HERE, "golden", "make_ref_goldens.py"))
+G = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(G)
+
+
+def load(name):
+    return np.load(os.path.join(HERE, "golden", name), allow_pickle=False)
+
+
+def shapes(z, mbc):
+    mx, my = int(z["mx"]), int(z["my"])
+    return mx, my, (mx + 2 * mbc, my + 2 * mbc), float(z["dx"]), float(z["dy"]), float(z["dt"])
+
+
+@pytest.mark.parametrize("trans", [0, 1, 2])
+def test_oracle_step2_unsplit(coracle, trans):
+    z = load("ref_step2_unsplit.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 2)
+    q0 = G.euler_state(10 + trans, shape)
+    qn = q0.copy("F")
+    method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
+    _, cfl = coracle.step2(O.RP_EULER5_2D, G.PAR, max(mx, my), 2, mx, my, q0.copy("F"), qn, None, dx, dy, dt, method, G.MTH)
+    assert np.array_equal(qn, z["q_trans%d" % trans]) and cfl == float(z["cfl_trans%d" % trans])
+
+
+@pytest.mark.parametrize("ids", [1, 2])
+def test_oracle_step2ds_capa(coracle, ids):
+    z = load("ref_step2ds_capa.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 2)
+    q0, aux = G.euler_state(20 + ids, shape), G.capa_field(20 + ids, shape)
+    qn = q0.copy("F")
+    method = np.array([1, 2, -1, 0, 0, 2, 2], dtype=np.int32)
+    _, cfl = coracle.step2ds(O.RP_EULER5_2D, G.PAR, max(mx, my), 2, mx, my, q0.copy("F"), qn, aux, dx, dy, dt, method,
+                             G.MTH, ids)
+    assert np.array_equal(qn, z["q_ids%d" % ids]) and cfl == float(z["cfl_ids%d" % ids])
+
+
+@pytest.mark.parametrize("lim", [2, 3])
+def test_oracle_sharp_flux2(coracle, lim):
+    z = load("ref_sharp_flux2.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 3)
+    q0 = G.euler_state(30 + lim, shape)
+    dq, cfl = coracle.sharp_flux2(O.RP_EULER5_2D, G.PAR, lim, 5, 0, 3, mx, my, q0, None, dx, dy, dt)
+    assert np.array_equal(dq[:, 3:-3, 3:-3], z["dq_lim%d" % lim]) and cfl == float(z["cfl_lim%d" % lim])
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("trans", [0, 1, 2])
+def test_hip_step2_unsplit(trans):
+    from pyclaw_amd import _lib as L
+    z = load("ref_step2_unsplit.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 2)
+    q0 = G.euler_state(10 + trans, shape)
+    out = q0.copy("F")
+    method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
+    mth = np.array(G.MTH, dtype=np.int32)
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(np.array(G.PAR)), 0, 5, 5, 0, 2, mx, my, L.d(q0), L.d(out), None,
+                              dx, dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None), slice(2, -2), slice(2, -2))
+    assert np.array_equal(out[inner], z["q_trans%d" % trans][inner]) and cfl.value == float(z["cfl_trans%d" % trans])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ids", [1, 2])
+def test_hip_step2ds_capa(ids):
+    from pyclaw_amd import _lib as L
+    z = load("ref_step2ds_capa.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 2)
+    q0, aux = G.euler_state(20 + ids, shape), G.capa_field(20 + ids, shape)
+    out = q0.copy("F")
+    method = np.array([1, 2, -1, 0, 0, 2, 2], dtype=np.int32)
+    mth = np.array(G.MTH, dtype=np.int32)
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(np.array(G.PAR)), 0, 5, 5, 2, 2, mx, my, L.d(q0), L.d(out),
+                                L.d(aux), dx, dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp), ids))
+    assert np.array_equal(out, z["q_ids%d" % ids]) and cfl.value == float(z["cfl_ids%d" % ids])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lim", [2, 3])
+def test_hip_sharp_flux2(lim):
+    from pyclaw_amd import _lib as L
+    z = load("ref_sharp_flux2.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 3)
+    q0 = G.euler_state(30 + lim, shape)
+    dq = np.zeros_like(q0)
+    cfl = C.c_double()
+    L.check(L.lib().pcl_sharp_flux2(O.RP_EULER5_2D, L.d(np.array(G.PAR + [0.0] * 6)), lim, 5, 5, 0, 0, 3, mx, my,
+                                    L.d(q0), L.d(dq), None, dx, dy, dt, C.cast(C.byref(cfl), L.dp)))
+    assert np.array_equal(dq[:, 3:-3, 3:-3], z["dq_lim%d" % lim]) and cfl.value == float(z["cfl_lim%d" % lim])
