@@ -138,6 +138,8 @@ public:
         return 0;
     }
 
+    bool has(int d) const { return active && plan_.nbr[d] >= 0; }
+
     // exchange the ghost frame of an nm-component SoA array
     // `on`: stream to enqueue on (default: the solver stream given to init)
     int exchange(double *q, int nm, long pitch, long plane, std::string &err, hipStream_t on = nullptr) {

@@ -93,7 +93,7 @@ int launch_sweep3(const SweepLaunch &l, std::string &err) {
 }
 
 #if !PCL_FAST
-bool x_interior_box(const SweepArgs &a, int box[4]) {
+bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]) {
     using T = TileShape<1>;
     constexpr int ADV = T::NSTRIP * STRIP;  // cells a tile advances along the row
     const int ntb = (a.J + T::ACROSS - 1) / T::ACROSS, nta = (a.mx + ADV - 1) / ADV;
@@ -103,6 +103,8 @@ bool x_interior_box(const SweepArgs &a, int box[4]) {
     box[2] = (HALO + ADV - 1) / ADV;
     const int room = a.I - a.mbc - T::ALONG - (a.mbc - HALO);  // ADV*ta <= room
     box[3] = room < 0 ? 0 : std::min(nta, room / ADV + 1);
+    ntiles[0] = ntb;
+    ntiles[1] = nta;
     return box[0] < box[1] && box[2] < box[3];
 }
 #endif

@@ -844,9 +844,17 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     const bool fused = s->cfg.meqn <= 8 && (s->cfg.ndim == 1 || (s->cfg.ndim == 2 && s->cfg.method[2] < 0));
     // Decomposed dim-split 2-D step: the halo exchange runs on its own stream while the x pass does the
     // tiles that read no ghost cell; the rim tiles follow once the ghost frame has arrived.
-    int box[4];
+    int box[4], ntiles[2];
     const bool overlapped = s->halo.active && fused && s->cfg.ndim == 2 && s->overlap && s->sel == 0 &&
-                            pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, dt), box);
+                            pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, dt), box, ntiles);
+    if (overlapped) {
+        // a side without a neighbour block gets its ghost cells from the boundary conditions the kernel evaluates
+        // while loading -- nothing there waits for the exchange, so the interior box reaches that edge
+        if (!s->halo.has(pcl::S)) box[0] = 0;
+        if (!s->halo.has(pcl::N)) box[1] = ntiles[0];
+        if (!s->halo.has(pcl::W)) box[2] = 0;
+        if (!s->halo.has(pcl::E)) box[3] = ntiles[1];
+    }
     if (s->halo.active && !overlapped) {
         std::string err;
         if (s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);

@@ -90,7 +90,8 @@ struct SweepLaunch {
 namespace exact {
 int launch_sweep(const SweepLaunch &l, std::string &err);
 // x-pass tiles [tb_lo,tb_hi) x [ta_lo,ta_hi) that read no ghost cell; false if there are none
-bool x_interior_box(const SweepArgs &a, int box[4]);
+// ntiles[0], ntiles[1] = row tiles / tiles along a row of the x pass
+bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]);
 int launch_sweep3(const SweepLaunch &l, std::string &err);   // 3-D dim-split sweep, l.ids = direction 1..3
 int launch_slices(const SweepLaunch &l, std::string &err);   // unsplit: per-slice pieces -> scratch
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);

@@ -221,3 +221,53 @@ def test_3d_self_halo_equals_periodic(shape):
     assert res[0][1] == res[1][1] and res[0][1][0] > 0
     assert np.array_equal(res[0][0], res[1][0])
     assert not np.array_equal(res[0][0], q0)
+
+
+@pytest.mark.parametrize("overlap", [1, 2])
+@pytest.mark.parametrize("axis", ["x", "y"])
+def test_overlapped_step_partial_neighbours(axis, overlap, monkeypatch):
+    """Neighbours on one axis only (self, periodic strip); the other axis has physical BCs (reflecting lower,
+    outflow upper) evaluated inside the x pass.  The interior box then reaches the sides without a neighbour.
+    == the same steps without a communicator and local periodic fills on that axis, bit for bit; overlap=2 is
+    the deterministic race check over a NaN-poisoned ghost frame."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    monkeypatch.setenv("PCL_HALO_OVERLAP", str(overlap))
+    mx, my, g = 1210, 41, 2
+    rng = np.random.default_rng(5)
+    q0 = np.empty((5, mx, my), order="F")
+    q0[0] = 1 + 0.3 * rng.random((mx, my))
+    q0[1] = 0.3 * rng.standard_normal((mx, my))
+    q0[2] = 0.2 * rng.standard_normal((mx, my))
+    q0[3] = 2.5 + 0.5 * rng.random((mx, my))
+    q0[4] = rng.random((mx, my))
+    res = []
+    for with_comm in (False, True):
+        h = make_solver(L, mx, my)
+        try:
+            if axis == "x":
+                nbr = np.array([0, 0, -1, -1, -1, -1, -1, -1], dtype=np.int32)
+                bc_comm, bc_loc = [-1, -1, 3, 1], [2, 2, 3, 1]
+            else:
+                nbr = np.array([-1, -1, 0, 0, -1, -1, -1, -1], dtype=np.int32)
+                bc_comm, bc_loc = [3, 1, -1, -1], [3, 1, 2, 2]
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(nbr)))
+            bc = np.array(bc_comm if with_comm else bc_loc, dtype=np.int32)
+            poison = np.full((5, mx + 2 * g, my + 2 * g), np.nan, order="F")
+            L.check(lib.pcl_put_q(h, L.d(poison), 1))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            cfls = []
+            for _ in range(3):
+                cfl = C.c_double()
+                L.check(lib.pcl_bc_step(h, L.i(bc), L.d(np.zeros(32)), 2e-5, C.cast(C.byref(cfl), L.dp)))
+                cfls.append(cfl.value)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            res.append((out, cfls))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and res[0][1][0] > 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
