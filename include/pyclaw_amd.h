@@ -49,8 +49,10 @@ extern "C" {
  * id plus the cparam values in declaration order. */
 #define PCL_RP_ADVECTION_1D 1 /* rp1_advection.f            cparam: u                   */
 #define PCL_RP_ACOUSTICS_1D 2 /* rp1_acoustics.f            cparam: rho,bulk,cc,zz      */
+#define PCL_RP_BURGERS_1D 3     /* rp1_burgers.f90 (transonic entropy fix); no cparam            */
 #define PCL_RP_ACOUSTICS_2D 10 /* rpn2/rpt2_acoustics.f     cparam: rho,bulk,cc,zz      */
 #define PCL_RP_EULER5_2D 11    /* rpn2/rpt2_euler_5wave.f   cparam: gamma,gamma1        */
+#define PCL_RP_ADVECTION_2D 12  /* rpn2/rpt2_advection.f      cparam: u,v                  */
 #define PCL_RP_VC_ACOUSTICS_3D 20 /* rpn3_vc_acoustics.f (test/acoustics/3d/Makefile); aux(1)=Z, aux(2)=c; dim-split only */
 
 /* boundary condition types = pyclaw.BC (src/pyclaw/solver.py:17-23) */

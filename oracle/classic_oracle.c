@@ -27,6 +27,8 @@
  * Riemann solvers whose source is NOT in the reference tree (third-party
  * clawpack/riemann, unpinned; named in the app Makefiles only) are restated
  * from their published algorithm: rp1_advection, rp1_acoustics,
+ * rp1_burgers, rpn2_advection, rpt2_advection (named by apps/burgers/1d/Makefile, apps/advection/2d/Makefile;
+ * no golden in the reference: parity unpinned at the Riemann-solver boundary),
  * rpn2_acoustics, rpt2_acoustics, rpn3_vc_acoustics (the reference's test/acoustics/3d/Makefile names
  * $(RIEMANN)/src/rpn3_vc_acoustics.f; pinned only through the scalar result 0.00286 +- 1e-4 of
  * test_3D_acoustics_homogeneous, test/test_examples.py:481-488).  rpn2_acoustics is pinned through the
@@ -44,6 +46,8 @@
 #define RP_ACOUSTICS_1D 2
 #define RP_ACOUSTICS_2D 10
 #define RP_EULER5_2D 11
+#define RP_BURGERS_1D 3
+#define RP_ADVECTION_2D 12
 #define RP_VC_ACOUSTICS_3D 20
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
@@ -137,6 +141,47 @@ static void rp1_acoustics(int meqn, int mwaves, int mbc, int mx, const double *q
             A2(amdq, m, i) = S(1, i) * W(m, 1, i);
             A2(apdq, m, i) = S(2, i) * W(m, 2, i);
         }
+    }
+}
+
+/* 1-D Burgers' equation q_t + (q^2/2)_x = 0 with the transonic entropy fix, restated (third-party rp1_burgers.f90) */
+static void rp1_burgers(int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                        double *wave, double *s, double *amdq, double *apdq, const double *par)
+{
+    (void)par;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        double qL = A2(qr, 1, i - 1), qR = A2(ql, 1, i);
+        W(1, 1, i) = qR - qL;
+        S(1, i) = 0.5 * (qL + qR);
+        A2(amdq, 1, i) = dmin(S(1, i), 0.0) * W(1, 1, i);
+        A2(apdq, 1, i) = dmax(S(1, i), 0.0) * W(1, 1, i);
+        if (qR > 0.0 && qL < 0.0) {          /* transonic rarefaction */
+            A2(amdq, 1, i) = -0.5 * (qL * qL);
+            A2(apdq, 1, i) = 0.5 * (qR * qR);
+        }
+    }
+}
+
+/* 2-D constant-coefficient advection q_t + u q_x + v q_y = 0, restated (third-party rpn2_advection.f /
+ * rpt2_advection.f); par = u, v */
+static void rpn2_advection(int ixy, int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                           double *wave, double *s, double *amdq, double *apdq, const double *par)
+{
+    double vel = par[ixy - 1];
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        W(1, 1, i) = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        S(1, i) = vel;
+        A2(amdq, 1, i) = dmin(vel, 0.0) * W(1, 1, i);
+        A2(apdq, 1, i) = dmax(vel, 0.0) * W(1, 1, i);
+    }
+}
+static void rpt2_advection(int ixy, int meqn, int mbc, int mx, const double *asdq, double *bmasdq,
+                           double *bpasdq, const double *par)
+{
+    double stran = par[2 - ixy];             /* the OTHER velocity */
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        A2(bmasdq, 1, i) = dmin(stran, 0.0) * A2(asdq, 1, i);
+        A2(bpasdq, 1, i) = dmax(stran, 0.0) * A2(asdq, 1, i);
     }
 }
 
@@ -395,6 +440,9 @@ static int rpn2_dispatch(int rp, int ixy, int meqn, int mwaves, int mbc, int mx,
                          double *apdq, const double *par)
 {
     switch (rp) {
+    case RP_ADVECTION_2D:
+        rpn2_advection(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
+        return 0;
     case RP_ACOUSTICS_2D:
         rpn2_acoustics(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
@@ -410,6 +458,9 @@ static int rpt2_dispatch(int rp, int ixy, int meqn, int mbc, int mx, const doubl
                          const double *par)
 {
     switch (rp) {
+    case RP_ADVECTION_2D:
+        rpt2_advection(ixy, meqn, mbc, mx, asdq, bmasdq, bpasdq, par);
+        return 0;
     case RP_ACOUSTICS_2D:
         rpt2_acoustics(ixy, meqn, mbc, mx, asdq, bmasdq, bpasdq, par);
         return 0;
@@ -726,6 +777,7 @@ int orc_step1(int rp, const double *par, int meqn, int mwaves, int maux, int mbc
     switch (rp) {
     case RP_ADVECTION_1D: rp1_advection(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
     case RP_ACOUSTICS_1D: rp1_acoustics(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
+    case RP_BURGERS_1D: rp1_burgers(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
     default: rc = -1;
     }
     if (!rc) {
@@ -780,6 +832,7 @@ int orc_rp1_ptr(int rp, const double *par, int meqn, int mwaves, int mbc, int mx
     switch (rp) {
     case RP_ADVECTION_1D: rp1_advection(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
     case RP_ACOUSTICS_1D: rp1_acoustics(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
+    case RP_BURGERS_1D: rp1_burgers(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
     }
     return -1;
 }

@@ -61,14 +61,17 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
     if (l.ndim == 1) {
         if (rp == PCL_RP_ADVECTION_1D) return launch<Advection1D, 1, true>(l, err);
         if (rp == PCL_RP_ACOUSTICS_1D) return launch<Acoustics1D, 1, true>(l, err);
+        if (rp == PCL_RP_BURGERS_1D) return launch<Burgers1D, 1, true>(l, err);
         err = "Riemann solver id is not a 1-D solver";
         return PCL_EINVAL;
     }
     if (l.ids == 1) {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false>(l, err);
+        if (rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 1, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false>(l, err);
+        if (rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 2, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -115,9 +118,11 @@ int launch_slices(const SweepLaunch &l, std::string &err) {
     if (l.ndim != 2) { err = "step2 is 2-D"; return PCL_EINVAL; }
     if (l.ids == 1) {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false, true>(l, err);
+        if (l.rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false, true>(l, err);
     } else {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false, true>(l, err);
+        if (l.rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false, true>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -156,6 +161,7 @@ template <class RP> int launch_unsplit_t(const SweepLaunch &l, const double *qx,
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
     if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
     if (l.rp == PCL_RP_ACOUSTICS_2D) return launch_unsplit_t<Acoustics2D>(l, qx, err);
+    if (l.rp == PCL_RP_ADVECTION_2D) return launch_unsplit_t<Advection2D>(l, qx, err);
     if (l.rp == PCL_RP_EULER5_2D) return launch_unsplit_t<Euler5>(l, qx, err);
     err = "Riemann solver id is not a 2-D solver";
     return PCL_EINVAL;
@@ -198,11 +204,14 @@ int launch_sharp(const SweepLaunch &l, std::string &err) {
     if (l.ndim == 1) {
         if (rp == PCL_RP_ADVECTION_1D) return launch_sharp_t<Advection1D, 1>(l, err);
         if (rp == PCL_RP_ACOUSTICS_1D) return launch_sharp_t<Acoustics1D, 1>(l, err);
+        if (rp == PCL_RP_BURGERS_1D) return launch_sharp_t<Burgers1D, 1>(l, err);
     } else if (l.ids == 1) {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 1>(l, err);
+        if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 1>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 1>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 2>(l, err);
+        if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 2>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 2>(l, err);
     }
     err = "Riemann solver id does not match the grid dimension";

@@ -125,6 +125,67 @@ struct Advection1D {
 };
 
 // ------------------------------------------------------------------------------------
+// 1-D Burgers' equation with the transonic entropy fix (third-party rp1_burgers.f90, restated)
+// ------------------------------------------------------------------------------------
+struct Burgers1D {
+    static constexpr int MEQN = 1, MWAVES = 1, NCELL = 1, NAUX = 0;
+    struct Cell { double q[1]; };
+    template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &) {
+        Cell c; c.q[0] = q[0]; return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &,
+                                                 double (&wave)[1][1], double (&s)[1],
+                                                 double (&amdq)[1], double (&apdq)[1]) {
+        wave[0][0] = R.q[0] - L.q[0];
+        s[0] = 0.5 * (L.q[0] + R.q[0]);
+        const bool transonic = R.q[0] > 0.0 && L.q[0] < 0.0;
+        amdq[0] = transonic ? -0.5 * (L.q[0] * L.q[0]) : dmin(s[0], 0.0) * wave[0][0];
+        apdq[0] = transonic ? 0.5 * (R.q[0] * R.q[0]) : dmax(s[0], 0.0) * wave[0][0];
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &, double (&s)[1]) {
+        s[0] = 0.5 * (L.q[0] + R.q[0]);
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// 2-D constant-coefficient advection (third-party rpn2_advection.f / rpt2_advection.f, restated); par = u, v
+// ------------------------------------------------------------------------------------
+struct Advection2D {
+    static constexpr int MEQN = 1, MWAVES = 1, NCELL = 1, NAUX = 0;
+    struct Cell { double q[1]; };
+    template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &) {
+        Cell c; c.q[0] = q[0]; return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &p,
+                                                 double (&wave)[1][1], double (&s)[1],
+                                                 double (&amdq)[1], double (&apdq)[1]) {
+        const double vel = p.v[IXY - 1];
+        wave[0][0] = R.q[0] - L.q[0];
+        s[0] = vel;
+        amdq[0] = dmin(vel, 0.0) * wave[0][0];
+        apdq[0] = dmax(vel, 0.0) * wave[0][0];
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &, const Cell &, const RpParams &p, double (&s)[1]) {
+        s[0] = p.v[IXY - 1];
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void transverse(const Cell &, const Cell &, const RpParams &p,
+                                                      const double (&asdq)[1], double (&bm)[1], double (&bp)[1]) {
+        const double stran = p.v[2 - IXY];
+        bm[0] = dmin(stran, 0.0) * asdq[0];
+        bp[0] = dmax(stran, 0.0) * asdq[0];
+    }
+};
+
+// ------------------------------------------------------------------------------------
 // 1-D acoustics (third-party rp1_acoustics.f, restated); par = rho,bulk,cc,zz
 // ------------------------------------------------------------------------------------
 struct Acoustics1D {
