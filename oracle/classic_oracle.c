@@ -27,7 +27,8 @@
  * Riemann solvers whose source is NOT in the reference tree (third-party
  * clawpack/riemann, unpinned; named in the app Makefiles only) are restated
  * from their published algorithm: rp1_advection, rp1_acoustics,
- * rp1_burgers, rpn2_advection, rpt2_advection (named by apps/burgers/1d/Makefile, apps/advection/2d/Makefile;
+ * rp1_euler_with_efix, rp1_shallow_roe_with_efix (apps/euler/1d, apps/shallow/1d Makefiles; restated like the
+ * vendored 2-D Euler solver they share their structure with), rp1_burgers, rpn2_advection, rpt2_advection (named by apps/burgers/1d/Makefile, apps/advection/2d/Makefile;
  * no golden in the reference: parity unpinned at the Riemann-solver boundary),
  * rpn2_acoustics, rpt2_acoustics, rpn3_vc_acoustics (the reference's test/acoustics/3d/Makefile names
  * $(RIEMANN)/src/rpn3_vc_acoustics.f; pinned only through the scalar result 0.00286 +- 1e-4 of
@@ -47,6 +48,8 @@
 #define RP_ACOUSTICS_2D 10
 #define RP_EULER5_2D 11
 #define RP_BURGERS_1D 3
+#define RP_EULER_1D 4
+#define RP_SHALLOW_1D 5
 #define RP_ADVECTION_2D 12
 #define RP_VC_ACOUSTICS_3D 20
 
@@ -158,6 +161,119 @@ static void rp1_burgers(int meqn, int mwaves, int mbc, int mx, const double *ql,
         if (qR > 0.0 && qL < 0.0) {          /* transonic rarefaction */
             A2(amdq, 1, i) = -0.5 * (qL * qL);
             A2(apdq, 1, i) = 0.5 * (qR * qR);
+        }
+    }
+}
+
+/* 1-D Euler equations, Roe solver with the Harten-Hyman entropy fix, restated (third-party rp1_euler_with_efix.f;
+ * same structure as the vendored rpn2_euler_5wave.f without the shear and tracer waves); par = gamma, gamma1 */
+static void rp1_euler(int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                      double *wave, double *s, double *amdq, double *apdq, const double *par)
+{
+    const double gamma = par[0], gamma1 = par[1];
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const double rl = A2(qr, 1, i - 1), ml = A2(qr, 2, i - 1), el = A2(qr, 3, i - 1);
+        const double rr = A2(ql, 1, i), mr = A2(ql, 2, i), er = A2(ql, 3, i);
+        const double rsl = sqrt(rl), rsr = sqrt(rr);
+        const double pl = gamma1 * (el - 0.5 * (ml * ml) / rl), pr = gamma1 * (er - 0.5 * (mr * mr) / rr);
+        const double rhsq2 = rsl + rsr;
+        const double u = (ml / rsl + mr / rsr) / rhsq2;
+        const double enth = ((el + pl) / rsl + (er + pr) / rsr) / rhsq2;
+        const double a2r = gamma1 * (enth - .5 * (u * u));
+        const double a = sqrt(a2r);
+        const double d1 = rr - rl, d2 = mr - ml, d3 = er - el;
+        const double a2 = gamma1 / a2r * ((enth - u * u) * d1 + u * d2 - d3);
+        const double a3 = (d2 + (a - u) * d1 - a * a2) / (2.0 * a);
+        const double a1 = d1 - a2 - a3;
+        W(1, 1, i) = a1; W(2, 1, i) = a1 * (u - a); W(3, 1, i) = a1 * (enth - u * a); S(1, i) = u - a;
+        W(1, 2, i) = a2; W(2, 2, i) = a2 * u;       W(3, 2, i) = a2 * 0.5 * (u * u);  S(2, i) = u;
+        W(1, 3, i) = a3; W(2, 3, i) = a3 * (u + a); W(3, 3, i) = a3 * (enth + u * a); S(3, i) = u + a;
+        /* entropy fix */
+        const double cl = sqrt(gamma * pl / rl);
+        const double s0 = ml / rl - cl;
+        int done = 0;
+        if (s0 >= 0.0 && S(1, i) > 0.0) {
+            for (int m = 1; m <= 3; m++) A2(amdq, m, i) = 0.0;
+            done = 1;
+        }
+        if (!done) {
+            const double rho1 = rl + W(1, 1, i), rhou1 = ml + W(2, 1, i), en1 = el + W(3, 1, i);
+            const double p1 = gamma1 * (en1 - 0.5 * (rhou1 * rhou1) / rho1);
+            const double c1 = sqrt(gamma * p1 / rho1);
+            const double s1 = rhou1 / rho1 - c1;
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0) sfract = s0 * (s1 - S(1, i)) / (s1 - s0);
+            else if (S(1, i) < 0.0) sfract = S(1, i);
+            else sfract = 0.0;
+            for (int m = 1; m <= 3; m++) A2(amdq, m, i) = sfract * W(m, 1, i);
+            if (!(S(2, i) >= 0.0)) {
+                for (int m = 1; m <= 3; m++) A2(amdq, m, i) = A2(amdq, m, i) + S(2, i) * W(m, 2, i);
+                const double cr = sqrt(gamma * pr / rr);
+                const double s3 = mr / rr + cr;
+                const double rho2 = rr - W(1, 3, i), rhou2 = mr - W(2, 3, i), en2 = er - W(3, 3, i);
+                const double p2 = gamma1 * (en2 - 0.5 * (rhou2 * rhou2) / rho2);
+                const double c2 = sqrt(gamma * p2 / rho2);
+                const double s2 = rhou2 / rho2 + c2;
+                int add = 1;
+                if (s2 < 0.0 && s3 > 0.0) sfract = s2 * (s3 - S(3, i)) / (s3 - s2);
+                else if (S(3, i) < 0.0) sfract = S(3, i);
+                else add = 0;
+                if (add) for (int m = 1; m <= 3; m++) A2(amdq, m, i) = A2(amdq, m, i) + sfract * W(m, 3, i);
+            }
+        }
+        for (int m = 1; m <= 3; m++) {
+            double df = 0.0;
+            for (int mw = 1; mw <= 3; mw++) df = df + S(mw, i) * W(m, mw, i);
+            A2(apdq, m, i) = df - A2(amdq, m, i);
+        }
+    }
+}
+
+/* 1-D shallow water equations, Roe solver with the Harten-Hyman entropy fix, restated (third-party
+ * rp1_shallow_roe_with_efix.f); q = (h, hu); par = g */
+static void rp1_shallow(int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                        double *wave, double *s, double *amdq, double *apdq, const double *par)
+{
+    const double g = par[0];
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const double hl = A2(qr, 1, i - 1), ml = A2(qr, 2, i - 1), hr = A2(ql, 1, i), mr = A2(ql, 2, i);
+        const double hsl = sqrt(hl), hsr = sqrt(hr);
+        const double ubar = (ml / hsl + mr / hsr) / (hsl + hsr);
+        const double cbar = sqrt(0.5 * g * (hl + hr));
+        const double d1 = hr - hl, d2 = mr - ml;
+        const double a1 = 0.5 * (-d2 + (ubar + cbar) * d1) / cbar;
+        const double a2 = 0.5 * (d2 - (ubar - cbar) * d1) / cbar;
+        W(1, 1, i) = a1; W(2, 1, i) = a1 * (ubar - cbar); S(1, i) = ubar - cbar;
+        W(1, 2, i) = a2; W(2, 2, i) = a2 * (ubar + cbar); S(2, i) = ubar + cbar;
+        /* entropy fix: 1-wave */
+        const double s0 = ml / hl - sqrt(g * hl);
+        int done = 0;
+        if (s0 >= 0.0 && S(1, i) > 0.0) {
+            A2(amdq, 1, i) = 0.0; A2(amdq, 2, i) = 0.0;
+            done = 1;
+        }
+        if (!done) {
+            const double h1 = hl + W(1, 1, i), hu1 = ml + W(2, 1, i);
+            const double s1 = hu1 / h1 - sqrt(g * h1);
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0) sfract = s0 * (s1 - S(1, i)) / (s1 - s0);
+            else if (S(1, i) < 0.0) sfract = S(1, i);
+            else sfract = 0.0;
+            for (int m = 1; m <= 2; m++) A2(amdq, m, i) = sfract * W(m, 1, i);
+            /* 2-wave */
+            const double s3 = mr / hr + sqrt(g * hr);
+            const double h2 = hr - W(1, 2, i), hu2 = mr - W(2, 2, i);
+            const double s2 = hu2 / h2 + sqrt(g * h2);
+            int add = 1;
+            if (s2 < 0.0 && s3 > 0.0) sfract = s2 * (s3 - S(2, i)) / (s3 - s2);
+            else if (S(2, i) < 0.0) sfract = S(2, i);
+            else add = 0;
+            if (add) for (int m = 1; m <= 2; m++) A2(amdq, m, i) = A2(amdq, m, i) + sfract * W(m, 2, i);
+        }
+        for (int m = 1; m <= 2; m++) {
+            double df = 0.0;
+            for (int mw = 1; mw <= 2; mw++) df = df + S(mw, i) * W(m, mw, i);
+            A2(apdq, m, i) = df - A2(amdq, m, i);
         }
     }
 }
@@ -778,6 +894,8 @@ int orc_step1(int rp, const double *par, int meqn, int mwaves, int maux, int mbc
     case RP_ADVECTION_1D: rp1_advection(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
     case RP_ACOUSTICS_1D: rp1_acoustics(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
     case RP_BURGERS_1D: rp1_burgers(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
+    case RP_EULER_1D: rp1_euler(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
+    case RP_SHALLOW_1D: rp1_shallow(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
     default: rc = -1;
     }
     if (!rc) {
@@ -833,6 +951,8 @@ int orc_rp1_ptr(int rp, const double *par, int meqn, int mwaves, int mbc, int mx
     case RP_ADVECTION_1D: rp1_advection(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
     case RP_ACOUSTICS_1D: rp1_acoustics(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
     case RP_BURGERS_1D: rp1_burgers(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
+    case RP_EULER_1D: rp1_euler(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
+    case RP_SHALLOW_1D: rp1_shallow(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
     }
     return -1;
 }

@@ -24,6 +24,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 RP_ADVECTION_1D = 1
 RP_ACOUSTICS_1D = 2
 RP_BURGERS_1D = 3
+RP_EULER_1D = 4
+RP_SHALLOW_1D = 5
 RP_ACOUSTICS_2D = 10
 RP_ADVECTION_2D = 12
 RP_EULER5_2D = 11

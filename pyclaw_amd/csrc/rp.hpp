@@ -152,6 +152,155 @@ struct Burgers1D {
 };
 
 // ------------------------------------------------------------------------------------
+// 1-D Euler equations, Roe solver + Harten-Hyman entropy fix (third-party rp1_euler_with_efix.f, restated:
+// the vendored 2-D solver below without its shear and tracer waves); par = gamma, gamma1.
+// Plain IEEE operations in the order of the C restatement (oracle/classic_oracle.c: rp1_euler).
+// ------------------------------------------------------------------------------------
+struct Euler1D {
+    static constexpr int MEQN = 3, MWAVES = 3, NCELL = 3, NAUX = 0;
+    struct Cell { double q[3]; };
+    template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &) {
+        Cell c; c.q[0] = q[0]; c.q[1] = q[1]; c.q[2] = q[2]; return c;
+    }
+    struct Roe { double u, enth, a2r, a, pl, pr; };
+    __device__ static __forceinline__ Roe roe(const Cell &L, const Cell &R, double gamma1) {
+        Roe r;
+        const double rsl = dsqrt(L.q[0]), rsr = dsqrt(R.q[0]);
+        r.pl = gamma1 * (L.q[2] - 0.5 * (L.q[1] * L.q[1]) / L.q[0]);
+        r.pr = gamma1 * (R.q[2] - 0.5 * (R.q[1] * R.q[1]) / R.q[0]);
+        const double rhsq2 = rsl + rsr;
+        r.u = (L.q[1] / rsl + R.q[1] / rsr) / rhsq2;
+        r.enth = ((L.q[2] + r.pl) / rsl + (R.q[2] + r.pr) / rsr) / rhsq2;
+        r.a2r = gamma1 * (r.enth - .5 * (r.u * r.u));
+        r.a = dsqrt(r.a2r);
+        return r;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &par, double (&s)[3]) {
+        const Roe r = roe(L, R, par.v[1]);
+        s[0] = r.u - r.a; s[1] = r.u; s[2] = r.u + r.a;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &par,
+                                                 double (&wave)[3][3], double (&s)[3], double (&amdq)[3],
+                                                 double (&apdq)[3]) {
+        const double gamma = par.v[0], gamma1 = par.v[1];
+        const Roe r = roe(L, R, gamma1);
+        const double u = r.u, enth = r.enth, a = r.a;
+        const double rl = L.q[0], ml = L.q[1], el = L.q[2], rr = R.q[0], mr = R.q[1], er = R.q[2];
+        const double d1 = rr - rl, d2 = mr - ml, d3 = er - el;
+        const double a2 = gamma1 / r.a2r * ((enth - u * u) * d1 + u * d2 - d3);
+        const double a3 = (d2 + (a - u) * d1 - a * a2) / (2.0 * a);
+        const double a1 = d1 - a2 - a3;
+        wave[0][0] = a1; wave[0][1] = a1 * (u - a); wave[0][2] = a1 * (enth - u * a); s[0] = u - a;
+        wave[1][0] = a2; wave[1][1] = a2 * u;       wave[1][2] = a2 * 0.5 * (u * u);  s[1] = u;
+        wave[2][0] = a3; wave[2][1] = a3 * (u + a); wave[2][2] = a3 * (enth + u * a); s[2] = u + a;
+        const double cl = dsqrt(gamma * r.pl / rl);
+        const double s0 = ml / rl - cl;
+        const bool all_right = (s0 >= 0.0) && (s[0] > 0.0);
+        {
+            const double rho1 = rl + wave[0][0], rhou1 = ml + wave[0][1], en1 = el + wave[0][2];
+            const double p1 = gamma1 * (en1 - 0.5 * (rhou1 * rhou1) / rho1);
+            const double c1 = dsqrt(gamma * p1 / rho1);
+            const double s1 = rhou1 / rho1 - c1;
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0) sfract = s0 * (s1 - s[0]) / (s1 - s0);
+            else if (s[0] < 0.0) sfract = s[0];
+            else sfract = 0.0;
+            for (int m = 0; m < 3; m++) amdq[m] = sfract * wave[0][m];
+        }
+        if (!(s[1] >= 0.0)) {
+            for (int m = 0; m < 3; m++) amdq[m] = amdq[m] + s[1] * wave[1][m];
+            const double cr = dsqrt(gamma * r.pr / rr);
+            const double s3 = mr / rr + cr;
+            const double rho2 = rr - wave[2][0], rhou2 = mr - wave[2][1], en2 = er - wave[2][2];
+            const double p2 = gamma1 * (en2 - 0.5 * (rhou2 * rhou2) / rho2);
+            const double c2 = dsqrt(gamma * p2 / rho2);
+            const double s2 = rhou2 / rho2 + c2;
+            double sfract = 0.0;
+            bool add = true;
+            if (s2 < 0.0 && s3 > 0.0) sfract = s2 * (s3 - s[2]) / (s3 - s2);
+            else if (s[2] < 0.0) sfract = s[2];
+            else add = false;
+            if (add) for (int m = 0; m < 3; m++) amdq[m] = amdq[m] + sfract * wave[2][m];
+        }
+        if (all_right) for (int m = 0; m < 3; m++) amdq[m] = 0.0;
+        for (int m = 0; m < 3; m++) {
+            double df = s[0] * wave[0][m];
+            df = df + s[1] * wave[1][m];
+            df = df + s[2] * wave[2][m];
+            apdq[m] = df - amdq[m];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// 1-D shallow water, Roe solver + Harten-Hyman entropy fix (third-party rp1_shallow_roe_with_efix.f, restated);
+// q = (h, hu); par = g.  Same operation order as oracle/classic_oracle.c: rp1_shallow.
+// ------------------------------------------------------------------------------------
+struct Shallow1D {
+    static constexpr int MEQN = 2, MWAVES = 2, NCELL = 2, NAUX = 0;
+    struct Cell { double q[2]; };
+    template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &) {
+        Cell c; c.q[0] = q[0]; c.q[1] = q[1]; return c;
+    }
+    __device__ static __forceinline__ void roe(const Cell &L, const Cell &R, double g, double &ubar, double &cbar) {
+        const double hsl = dsqrt(L.q[0]), hsr = dsqrt(R.q[0]);
+        ubar = (L.q[1] / hsl + R.q[1] / hsr) / (hsl + hsr);
+        cbar = dsqrt(0.5 * g * (L.q[0] + R.q[0]));
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &par, double (&s)[2]) {
+        double ubar, cbar;
+        roe(L, R, par.v[0], ubar, cbar);
+        s[0] = ubar - cbar; s[1] = ubar + cbar;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &par,
+                                                 double (&wave)[2][2], double (&s)[2], double (&amdq)[2],
+                                                 double (&apdq)[2]) {
+        const double g = par.v[0];
+        const double hl = L.q[0], ml = L.q[1], hr = R.q[0], mr = R.q[1];
+        double ubar, cbar;
+        roe(L, R, g, ubar, cbar);
+        const double d1 = hr - hl, d2 = mr - ml;
+        const double a1 = 0.5 * (-d2 + (ubar + cbar) * d1) / cbar;
+        const double a2 = 0.5 * (d2 - (ubar - cbar) * d1) / cbar;
+        wave[0][0] = a1; wave[0][1] = a1 * (ubar - cbar); s[0] = ubar - cbar;
+        wave[1][0] = a2; wave[1][1] = a2 * (ubar + cbar); s[1] = ubar + cbar;
+        const double s0 = ml / hl - dsqrt(g * hl);
+        const bool all_right = (s0 >= 0.0) && (s[0] > 0.0);
+        {
+            const double h1 = hl + wave[0][0], hu1 = ml + wave[0][1];
+            const double s1 = hu1 / h1 - dsqrt(g * h1);
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0) sfract = s0 * (s1 - s[0]) / (s1 - s0);
+            else if (s[0] < 0.0) sfract = s[0];
+            else sfract = 0.0;
+            for (int m = 0; m < 2; m++) amdq[m] = sfract * wave[0][m];
+            const double s3 = mr / hr + dsqrt(g * hr);
+            const double h2 = hr - wave[1][0], hu2 = mr - wave[1][1];
+            const double s2 = hu2 / h2 + dsqrt(g * h2);
+            bool add = true;
+            if (s2 < 0.0 && s3 > 0.0) sfract = s2 * (s3 - s[1]) / (s3 - s2);
+            else if (s[1] < 0.0) sfract = s[1];
+            else add = false;
+            if (add) for (int m = 0; m < 2; m++) amdq[m] = amdq[m] + sfract * wave[1][m];
+        }
+        if (all_right) for (int m = 0; m < 2; m++) amdq[m] = 0.0;
+        for (int m = 0; m < 2; m++) {
+            double df = s[0] * wave[0][m];
+            df = df + s[1] * wave[1][m];
+            apdq[m] = df - amdq[m];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
 // 2-D constant-coefficient advection (third-party rpn2_advection.f / rpt2_advection.f, restated); par = u, v
 // ------------------------------------------------------------------------------------
 struct Advection2D {

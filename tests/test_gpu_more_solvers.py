@@ -119,3 +119,110 @@ def test_burgers_app_shock_speed():
     front = xc[np.argmin(np.abs(q - 0.5))]
     assert abs(front - (0.25 + 0.5 * 0.5)) < 2.5 / 400
     assert q.max() <= 1.01 and q.min() >= -0.01                   # no spurious oscillation beyond the MC limiter's
+
+
+def _euler1d_state(rng, n, kind):
+    rho = 0.3 + rng.random(n)
+    u = 2.5 * (rng.random(n) - 0.5) if kind == "transonic" else 0.2 * rng.random(n)
+    p = 0.2 + rng.random(n)
+    if kind == "sod":
+        x = np.linspace(0, 1, n)
+        rho = np.where(x < 0.5, 3.0, 1.0)
+        u = np.where(x < 0.5, 0.9, 0.9)           # with u > 0 the 1-rarefaction is transonic
+        p = np.where(x < 0.5, 3.0, 1.0)
+    q = np.empty((3, n), order="F")
+    q[0], q[1], q[2] = rho, rho * u, p / 0.4 + 0.5 * rho * u * u
+    return q
+
+
+@pytest.mark.parametrize("kind", ["smooth", "transonic", "sod"])
+@pytest.mark.parametrize("mx", [50, 257])
+def test_euler1d_step1_and_sharpclaw(coracle, kind, mx):
+    from pyclaw_amd import _lib as L
+    rng = np.random.default_rng(mx)
+    par = np.array([1.4, 0.4] + [0.0] * 6)
+    method = np.array([1, 2, 0, 0, 0, 0, 0], dtype=np.int32)
+    mth = np.array([4, 4, 4], dtype=np.int32)
+    dx, dt = 1.0 / mx, 0.15 / mx
+    q = _euler1d_state(rng, mx + 4, kind)
+    ref = q.copy("F")
+    _, cfl_ref = coracle.step1(O.RP_EULER_1D, par, 2, mx, ref, None, dx, dt, method, mth)
+    out = q.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step1(O.RP_EULER_1D, L.d(par), 3, 3, 0, 2, mx, L.d(out), None, dx, dt, L.i(method), L.i(mth),
+                              C.cast(C.byref(cfl), L.dp)))
+    assert np.array_equal(out[:, 2:-2], ref[:, 2:-2]) and cfl.value == cfl_ref and np.isfinite(out).all()
+    assert not np.array_equal(out[:, 2:-2], q[:, 2:-2])
+    q3 = _euler1d_state(rng, mx + 6, kind)
+    ref, cfl_ref = coracle.sharp_flux1(O.RP_EULER_1D, par, 2, 3, 0, 3, mx, q3, None, dx, dt)
+    dq = np.zeros_like(q3)
+    L.check(L.lib().pcl_sharp_flux1(O.RP_EULER_1D, L.d(par), 2, 3, 3, 0, 0, 3, mx, L.d(q3), L.d(dq), None, dx, dt,
+                                    C.cast(C.byref(cfl), L.dp)))
+    assert np.array_equal(dq[:, 3:-3], ref[:, 3:-3]) and cfl.value == cfl_ref
+
+
+@pytest.mark.parametrize("kind", ["smooth", "transonic"])
+def test_shallow1d_step1_and_sharpclaw(coracle, kind):
+    from pyclaw_amd import _lib as L
+    mx = 300
+    rng = np.random.default_rng(4)
+    par = np.array([9.81] + [0.0] * 7)
+    method = np.array([1, 2, 0, 0, 0, 0, 0], dtype=np.int32)
+    mth = np.array([4, 4], dtype=np.int32)
+    dx, dt = 1.0 / mx, 0.05 / mx
+
+    def state(n):
+        h = 0.5 + rng.random(n)
+        u = 8.0 * (rng.random(n) - 0.5) if kind == "transonic" else 0.3 * rng.random(n)
+        q = np.empty((2, n), order="F")
+        q[0], q[1] = h, h * u
+        return q
+    q = state(mx + 4)
+    ref = q.copy("F")
+    _, cfl_ref = coracle.step1(O.RP_SHALLOW_1D, par, 2, mx, ref, None, dx, dt, method, mth)
+    out = q.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step1(O.RP_SHALLOW_1D, L.d(par), 2, 2, 0, 2, mx, L.d(out), None, dx, dt, L.i(method), L.i(mth),
+                              C.cast(C.byref(cfl), L.dp)))
+    assert np.array_equal(out[:, 2:-2], ref[:, 2:-2]) and cfl.value == cfl_ref and np.isfinite(out).all()
+    q3 = state(mx + 6)
+    ref, cfl_ref = coracle.sharp_flux1(O.RP_SHALLOW_1D, par, 3, 2, 0, 3, mx, q3, None, dx, dt)
+    dq = np.zeros_like(q3)
+    L.check(L.lib().pcl_sharp_flux1(O.RP_SHALLOW_1D, L.d(par), 3, 2, 2, 0, 0, 3, mx, L.d(q3), L.d(dq), None, dx, dt,
+                                    C.cast(C.byref(cfl), L.dp)))
+    assert np.array_equal(dq[:, 3:-3], ref[:, 3:-3]) and cfl.value == cfl_ref
+
+
+def test_sod_shock_tube_app():
+    """Sod's problem through ClawSolver1D + rp_euler_1d: contact and shock positions at t = 0.2 within two cells of
+    the exact solution (x_contact = 0.5 + 0.9275 t, x_shock = 0.5 + 1.7522 t), total mass conserved to rounding."""
+    import pyclaw_amd as pyclaw
+    solver = pyclaw.ClawSolver1D()
+    solver.rp = pyclaw.riemann.rp_euler_1d
+    solver.mwaves = 3
+    solver.limiters = [4, 4, 4]
+    solver.bc_lower[0] = solver.bc_upper[0] = pyclaw.BC.outflow
+    n = 800
+    state = pyclaw.State(pyclaw.Grid(pyclaw.Dimension('x', 0.0, 1.0, n)), 3)
+    state.aux_global['gamma'] = 1.4
+    state.aux_global['gamma1'] = 0.4
+    xc = state.grid.x.center
+    rho = np.where(xc < 0.5, 1.0, 0.125)
+    p = np.where(xc < 0.5, 1.0, 0.1)
+    state.q[0], state.q[1], state.q[2] = rho, 0.0, p / 0.4
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.solution = pyclaw.Solution(state)
+    claw.solver = solver
+    claw.tfinal, claw.nout = 0.2, 1
+    solver.dt_initial = 1e-4
+    claw.run()
+    q = claw.frames[1].state.q
+    assert abs(q[0].sum() - claw.frames[0].state.q[0].sum()) < 1e-10
+    drho = np.abs(np.diff(q[0]))
+    right = xc[:-1] > 0.8
+    x_shock = xc[:-1][right][np.argmax(drho[right])]
+    mid = (xc[:-1] > 0.6) & (xc[:-1] < 0.8)
+    x_contact = xc[:-1][mid][np.argmax(drho[mid])]
+    assert abs(x_shock - (0.5 + 1.7522 * 0.2)) < 3.0 / n
+    assert abs(x_contact - (0.5 + 0.9275 * 0.2)) < 4.0 / n
