@@ -27,7 +27,7 @@
  * Riemann solvers whose source is NOT in the reference tree (third-party
  * clawpack/riemann, unpinned; named in the app Makefiles only) are restated
  * from their published algorithm: rp1_advection, rp1_acoustics,
- * rp1_euler_with_efix, rp1_shallow_roe_with_efix (apps/euler/1d, apps/shallow/1d Makefiles; restated like the
+ * rpn2/rpt2_shallow_roe_with_efix (apps/shallow/2d/Makefile), rp1_euler_with_efix, rp1_shallow_roe_with_efix (apps/euler/1d, apps/shallow/1d Makefiles; restated like the
  * vendored 2-D Euler solver they share their structure with), rp1_burgers, rpn2_advection, rpt2_advection (named by apps/burgers/1d/Makefile, apps/advection/2d/Makefile;
  * no golden in the reference: parity unpinned at the Riemann-solver boundary),
  * rpn2_acoustics, rpt2_acoustics, rpn3_vc_acoustics (the reference's test/acoustics/3d/Makefile names
@@ -51,6 +51,7 @@
 #define RP_EULER_1D 4
 #define RP_SHALLOW_1D 5
 #define RP_ADVECTION_2D 12
+#define RP_SHALLOW_2D 13
 #define RP_VC_ACOUSTICS_3D 20
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
@@ -298,6 +299,94 @@ static void rpt2_advection(int ixy, int meqn, int mbc, int mx, const double *asd
     for (int i = 2 - mbc; i <= mx + mbc; i++) {
         A2(bmasdq, 1, i) = dmin(stran, 0.0) * A2(asdq, 1, i);
         A2(bpasdq, 1, i) = dmax(stran, 0.0) * A2(asdq, 1, i);
+    }
+}
+
+/* 2-D shallow water, Roe solver with the Harten-Hyman entropy fix and its transverse solver, restated
+ * (third-party rpn2_shallow_roe_with_efix.f / rpt2_shallow_roe_with_efix.f); q = (h, hu, hv); par = g */
+typedef struct { double h, u, v, a; } swroe_t;
+static inline swroe_t sw_roe(const double *ql, const double *qr, int meqn, int mbc, int i, int mu, int mv, double g)
+{
+    swroe_t r;
+    r.h = (A2(qr, 1, i - 1) + A2(ql, 1, i)) * 0.5;
+    const double hsl = sqrt(A2(qr, 1, i - 1)), hsr = sqrt(A2(ql, 1, i)), hsq2 = hsl + hsr;
+    r.u = (A2(qr, mu, i - 1) / hsl + A2(ql, mu, i) / hsr) / hsq2;
+    r.v = (A2(qr, mv, i - 1) / hsl + A2(ql, mv, i) / hsr) / hsq2;
+    r.a = sqrt(g * r.h);
+    return r;
+}
+static void rpn2_shallow(int ixy, int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                         double *wave, double *s, double *amdq, double *apdq, const double *par)
+{
+    const double g = par[0];
+    const int mu = (ixy == 1) ? 2 : 3, mv = (ixy == 1) ? 3 : 2;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const swroe_t r = sw_roe(ql, qr, meqn, mbc, i, mu, mv, g);
+        const double d1 = A2(ql, 1, i) - A2(qr, 1, i - 1), d2 = A2(ql, mu, i) - A2(qr, mu, i - 1);
+        const double d3 = A2(ql, mv, i) - A2(qr, mv, i - 1);
+        const double a1 = ((r.u + r.a) * d1 - d2) * (0.5 / r.a);
+        const double a2 = -r.v * d1 + d3;
+        const double a3 = (-(r.u - r.a) * d1 + d2) * (0.5 / r.a);
+        W(1, 1, i) = a1; W(mu, 1, i) = a1 * (r.u - r.a); W(mv, 1, i) = a1 * r.v; S(1, i) = r.u - r.a;
+        W(1, 2, i) = 0.0; W(mu, 2, i) = 0.0; W(mv, 2, i) = a2; S(2, i) = r.u;
+        W(1, 3, i) = a3; W(mu, 3, i) = a3 * (r.u + r.a); W(mv, 3, i) = a3 * r.v; S(3, i) = r.u + r.a;
+        const double hl = A2(qr, 1, i - 1), hr = A2(ql, 1, i);
+        const double s0 = A2(qr, mu, i - 1) / hl - sqrt(g * hl);
+        int done = 0;
+        if (s0 >= 0.0 && S(1, i) > 0.0) {
+            for (int m = 1; m <= 3; m++) A2(amdq, m, i) = 0.0;
+            done = 1;
+        }
+        if (!done) {
+            const double h1 = hl + W(1, 1, i), hu1 = A2(qr, mu, i - 1) + W(mu, 1, i);
+            const double s1 = hu1 / h1 - sqrt(g * h1);
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0) sfract = s0 * (s1 - S(1, i)) / (s1 - s0);
+            else if (S(1, i) < 0.0) sfract = S(1, i);
+            else sfract = 0.0;
+            for (int m = 1; m <= 3; m++) A2(amdq, m, i) = sfract * W(m, 1, i);
+            if (!(S(2, i) >= 0.0)) {
+                for (int m = 1; m <= 3; m++) A2(amdq, m, i) = A2(amdq, m, i) + S(2, i) * W(m, 2, i);
+                const double s03 = A2(ql, mu, i) / hr + sqrt(g * hr);
+                const double h3 = hr - W(1, 3, i), hu3 = A2(ql, mu, i) - W(mu, 3, i);
+                const double s3 = hu3 / h3 + sqrt(g * h3);
+                int add = 1;
+                if (s3 < 0.0 && s03 > 0.0) sfract = s3 * (s03 - S(3, i)) / (s03 - s3);
+                else if (S(3, i) < 0.0) sfract = S(3, i);
+                else add = 0;
+                if (add) for (int m = 1; m <= 3; m++) A2(amdq, m, i) = A2(amdq, m, i) + sfract * W(m, 3, i);
+            }
+        }
+        for (int m = 1; m <= 3; m++) {
+            double df = 0.0;
+            for (int mw = 1; mw <= 3; mw++) df = df + S(mw, i) * W(m, mw, i);
+            A2(apdq, m, i) = df - A2(amdq, m, i);
+        }
+    }
+}
+static void rpt2_shallow(int ixy, int meqn, int mbc, int mx, const double *q, const double *asdq,
+                         double *bmasdq, double *bpasdq, const double *par)
+{
+    const double g = par[0];
+    const int mu = (ixy == 1) ? 2 : 3, mv = (ixy == 1) ? 3 : 2;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const swroe_t r = sw_roe(q, q, meqn, mbc, i, mu, mv, g);
+        const double a1 = (0.5 / r.a) * ((r.v + r.a) * A2(asdq, 1, i) - A2(asdq, mv, i));
+        const double a2 = A2(asdq, mu, i) - r.u * A2(asdq, 1, i);
+        const double a3 = (0.5 / r.a) * (-(r.v - r.a) * A2(asdq, 1, i) + A2(asdq, mv, i));
+        double wb[4][4], sb[4];
+        wb[1][1] = a1; wb[mu][1] = a1 * r.u; wb[mv][1] = a1 * (r.v - r.a); sb[1] = r.v - r.a;
+        wb[1][2] = 0.0; wb[mu][2] = a2; wb[mv][2] = 0.0; sb[2] = r.v;
+        wb[1][3] = a3; wb[mu][3] = a3 * r.u; wb[mv][3] = a3 * (r.v + r.a); sb[3] = r.v + r.a;
+        for (int m = 1; m <= 3; m++) {
+            double bm = 0.0, bp = 0.0;
+            for (int mw = 1; mw <= 3; mw++) {
+                bm = bm + dmin(sb[mw], 0.0) * wb[m][mw];
+                bp = bp + dmax(sb[mw], 0.0) * wb[m][mw];
+            }
+            A2(bmasdq, m, i) = bm;
+            A2(bpasdq, m, i) = bp;
+        }
     }
 }
 
@@ -559,6 +648,9 @@ static int rpn2_dispatch(int rp, int ixy, int meqn, int mwaves, int mbc, int mx,
     case RP_ADVECTION_2D:
         rpn2_advection(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
+    case RP_SHALLOW_2D:
+        rpn2_shallow(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
+        return 0;
     case RP_ACOUSTICS_2D:
         rpn2_acoustics(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
@@ -576,6 +668,9 @@ static int rpt2_dispatch(int rp, int ixy, int meqn, int mbc, int mx, const doubl
     switch (rp) {
     case RP_ADVECTION_2D:
         rpt2_advection(ixy, meqn, mbc, mx, asdq, bmasdq, bpasdq, par);
+        return 0;
+    case RP_SHALLOW_2D:
+        rpt2_shallow(ixy, meqn, mbc, mx, q, asdq, bmasdq, bpasdq, par);
         return 0;
     case RP_ACOUSTICS_2D:
         rpt2_acoustics(ixy, meqn, mbc, mx, asdq, bmasdq, bpasdq, par);

@@ -70,10 +70,12 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
     if (l.ids == 1) {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false>(l, err);
         if (rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 1, false>(l, err);
+        if (rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 1, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false>(l, err);
         if (rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 2, false>(l, err);
+        if (rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 2, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -121,10 +123,12 @@ int launch_slices(const SweepLaunch &l, std::string &err) {
     if (l.ids == 1) {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 1, false, true>(l, err);
+        if (l.rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false, true>(l, err);
     } else {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 2, false, true>(l, err);
+        if (l.rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false, true>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -164,6 +168,7 @@ int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
     if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
     if (l.rp == PCL_RP_ACOUSTICS_2D) return launch_unsplit_t<Acoustics2D>(l, qx, err);
     if (l.rp == PCL_RP_ADVECTION_2D) return launch_unsplit_t<Advection2D>(l, qx, err);
+    if (l.rp == PCL_RP_SHALLOW_2D) return launch_unsplit_t<Shallow2D>(l, qx, err);
     if (l.rp == PCL_RP_EULER5_2D) return launch_unsplit_t<Euler5>(l, qx, err);
     err = "Riemann solver id is not a 2-D solver";
     return PCL_EINVAL;
@@ -212,10 +217,12 @@ int launch_sharp(const SweepLaunch &l, std::string &err) {
     } else if (l.ids == 1) {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 1>(l, err);
         if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 1>(l, err);
+        if (rp == PCL_RP_SHALLOW_2D) return launch_sharp_t<Shallow2D, 1>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 1>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 2>(l, err);
         if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 2>(l, err);
+        if (rp == PCL_RP_SHALLOW_2D) return launch_sharp_t<Shallow2D, 2>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 2>(l, err);
     }
     err = "Riemann solver id does not match the grid dimension";

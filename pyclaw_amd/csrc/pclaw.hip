@@ -512,6 +512,7 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     case PCL_RP_EULER_1D: want_meqn = 3; want_mwaves = 3; want_ndim = 1; break;
     case PCL_RP_SHALLOW_1D: want_meqn = 2; want_mwaves = 2; want_ndim = 1; break;
     case PCL_RP_ADVECTION_2D: want_meqn = 1; want_mwaves = 1; want_ndim = 2; break;
+    case PCL_RP_SHALLOW_2D: want_meqn = 3; want_mwaves = 3; want_ndim = 2; break;
     case PCL_RP_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
     case PCL_RP_EULER5_2D: want_meqn = 5; want_mwaves = 5; want_ndim = 2; break;
     case PCL_RP_VC_ACOUSTICS_3D: want_meqn = 4; want_mwaves = 2; want_ndim = 3; break;

@@ -450,6 +450,108 @@ struct VcAcoustics3D {
 };
 
 // ------------------------------------------------------------------------------------
+// 2-D shallow water, Roe solver + Harten-Hyman entropy fix and its transverse solver (third-party
+// rpn2_shallow_roe_with_efix.f / rpt2_shallow_roe_with_efix.f, restated); q = (h, hu, hv); par = g.
+// Plain IEEE operations in the order of oracle/classic_oracle.c: rpn2_shallow / rpt2_shallow.
+// ------------------------------------------------------------------------------------
+struct Shallow2D {
+    static constexpr int MEQN = 3, MWAVES = 3, NCELL = 3, NAUX = 0;
+    struct Cell { double q[3]; };
+    // wave(m,mw) sparsity: wave 2 carries only the transverse momentum
+    template <int IXY> __device__ static constexpr bool nz(int mw, int m) {
+        constexpr int mv = (IXY == 1) ? 2 : 1;
+        return mw == 1 ? (m == mv) : true;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &) {
+        Cell c; c.q[0] = q[0]; c.q[1] = q[1]; c.q[2] = q[2]; return c;
+    }
+    struct Roe { double h, u, v, a; };
+    template <int IXY> __device__ static __forceinline__ Roe roe(const Cell &L, const Cell &R, double g) {
+        constexpr int mu = (IXY == 1) ? 1 : 2, mv = (IXY == 1) ? 2 : 1;
+        Roe r;
+        r.h = (L.q[0] + R.q[0]) * 0.5;
+        const double hsl = dsqrt(L.q[0]), hsr = dsqrt(R.q[0]), hsq2 = hsl + hsr;
+        r.u = (L.q[mu] / hsl + R.q[mu] / hsr) / hsq2;
+        r.v = (L.q[mv] / hsl + R.q[mv] / hsr) / hsq2;
+        r.a = dsqrt(g * r.h);
+        return r;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &par, double (&s)[3]) {
+        const Roe r = roe<IXY>(L, R, par.v[0]);
+        s[0] = r.u - r.a; s[1] = r.u; s[2] = r.u + r.a;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &par,
+                                                 double (&wave)[3][3], double (&s)[3], double (&amdq)[3],
+                                                 double (&apdq)[3]) {
+        constexpr int mu = (IXY == 1) ? 1 : 2, mv = (IXY == 1) ? 2 : 1;
+        const double g = par.v[0];
+        const Roe r = roe<IXY>(L, R, g);
+        const double d1 = R.q[0] - L.q[0], d2 = R.q[mu] - L.q[mu], d3 = R.q[mv] - L.q[mv];
+        const double a1 = ((r.u + r.a) * d1 - d2) * (0.5 / r.a);
+        const double a2 = -r.v * d1 + d3;
+        const double a3 = (-(r.u - r.a) * d1 + d2) * (0.5 / r.a);
+        wave[0][0] = a1;  wave[0][mu] = a1 * (r.u - r.a); wave[0][mv] = a1 * r.v; s[0] = r.u - r.a;
+        wave[1][0] = 0.0; wave[1][mu] = 0.0;              wave[1][mv] = a2;       s[1] = r.u;
+        wave[2][0] = a3;  wave[2][mu] = a3 * (r.u + r.a); wave[2][mv] = a3 * r.v; s[2] = r.u + r.a;
+        const double hl = L.q[0], hr = R.q[0];
+        const double s0 = L.q[mu] / hl - dsqrt(g * hl);
+        const bool all_right = (s0 >= 0.0) && (s[0] > 0.0);
+        {
+            const double h1 = hl + wave[0][0], hu1 = L.q[mu] + wave[0][mu];
+            const double s1 = hu1 / h1 - dsqrt(g * h1);
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0) sfract = s0 * (s1 - s[0]) / (s1 - s0);
+            else if (s[0] < 0.0) sfract = s[0];
+            else sfract = 0.0;
+            for (int m = 0; m < 3; m++) amdq[m] = sfract * wave[0][m];
+        }
+        if (!(s[1] >= 0.0)) {
+            for (int m = 0; m < 3; m++) amdq[m] = amdq[m] + s[1] * wave[1][m];
+            const double s03 = R.q[mu] / hr + dsqrt(g * hr);
+            const double h3 = hr - wave[2][0], hu3 = R.q[mu] - wave[2][mu];
+            const double s3 = hu3 / h3 + dsqrt(g * h3);
+            double sfract = 0.0;
+            bool add = true;
+            if (s3 < 0.0 && s03 > 0.0) sfract = s3 * (s03 - s[2]) / (s03 - s3);
+            else if (s[2] < 0.0) sfract = s[2];
+            else add = false;
+            if (add) for (int m = 0; m < 3; m++) amdq[m] = amdq[m] + sfract * wave[2][m];
+        }
+        if (all_right) for (int m = 0; m < 3; m++) amdq[m] = 0.0;
+        for (int m = 0; m < 3; m++) {
+            double df = s[0] * wave[0][m];
+            df = df + s[1] * wave[1][m];
+            df = df + s[2] * wave[2][m];
+            apdq[m] = df - amdq[m];
+        }
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void transverse(const Cell &L, const Cell &R, const RpParams &par,
+                                                      const double (&asdq)[3], double (&bm)[3], double (&bp)[3]) {
+        constexpr int mu = (IXY == 1) ? 1 : 2, mv = (IXY == 1) ? 2 : 1;
+        const Roe r = roe<IXY>(L, R, par.v[0]);
+        const double a1 = (0.5 / r.a) * ((r.v + r.a) * asdq[0] - asdq[mv]);
+        const double a2 = asdq[mu] - r.u * asdq[0];
+        const double a3 = (0.5 / r.a) * (-(r.v - r.a) * asdq[0] + asdq[mv]);
+        double wb[3][3], sb[3];
+        wb[0][0] = a1;  wb[0][mu] = a1 * r.u; wb[0][mv] = a1 * (r.v - r.a); sb[0] = r.v - r.a;
+        wb[1][0] = 0.0; wb[1][mu] = a2;       wb[1][mv] = 0.0;              sb[1] = r.v;
+        wb[2][0] = a3;  wb[2][mu] = a3 * r.u; wb[2][mv] = a3 * (r.v + r.a); sb[2] = r.v + r.a;
+        for (int m = 0; m < 3; m++) {
+            double m_ = 0.0, p_ = 0.0;
+            for (int mw = 0; mw < 3; mw++) {
+                m_ = m_ + dmin(sb[mw], 0.0) * wb[mw][m];
+                p_ = p_ + dmax(sb[mw], 0.0) * wb[mw][m];
+            }
+            bm[m] = m_; bp[m] = p_;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
 // 2-D Euler, Roe solver with 5 waves (acoustic-, shear, entropy, acoustic+, tracer) and
 // the Harten-Hyman entropy fix: development/rp_approaches/rpn2_euler_5wave.f:87-298,
 // transverse split rpt2_euler_5wave_rec_loc.f:50-116.  par = gamma, gamma1.
