@@ -198,3 +198,20 @@ def test_restart_from_block_checkpoint(tmp_path):
     assert again.frames[-1].t == full.frames[4].t
     assert np.array_equal(again.frames[-1].state.q, full.frames[4].state.q)
     assert os.path.exists(os.path.join(again.outdir, "claw.ckpt0004.json"))
+
+
+@pytest.mark.parametrize("device_callbacks", [False, True])
+def test_shockbubble_multi_tile_replay(coracle, device_callbacks):
+    """The shock-bubble app on a 520 x 150 grid (several tiles in both directions, ragged edges) to t = 0.03:
+    source term, inflow/reflecting/outflow BCs, adaptive dt with its CFL feedback, the jump-free and
+    absent-family shortcuts -- every accepted/rejected step and the final state equal the oracle driver's
+    replay bit for bit (the reference's own golden, 160 x 40, is smaller than one x tile)."""
+    import pyclaw_amd as pyclaw
+    claw = problems.shockbubble(pyclaw, mx=520, my=150, tfinal=0.03, device_callbacks=device_callbacks,
+                                dt_initial=0.005 * 160.0 / 520.0)
+    p = D.shockbubble_problem(mx=520, my=150)
+    p.dt_initial = 0.005 * 160.0 / 520.0
+    st = D.run(p, coracle, 0.03, 1)[-1]
+    assert claw.solver.status['numsteps'] == st['numsteps'] and st['numsteps'] > 40
+    assert claw.solver.status['cflmax'] == st['cflmax'] and claw.solver.status['dtmin'] == st['dtmin']
+    assert np.array_equal(claw.frames[1].state.q, p.q)
