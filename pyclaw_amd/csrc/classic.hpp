@@ -565,6 +565,18 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     cfl_publish(a.cfl, cflmax);
 }
 
+// Workgroups are handed to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2.  Tiles that share
+// cache lines (the unsplit kernels' 60-cell / 14-column pieces are not line-aligned) should therefore run on
+// the SAME XCD, close in time, so that the shared lines are fetched once and the two partial-line stores merge
+// in that L2 before they go to HBM.  This maps blockIdx to a logical index such that each XCD walks a
+// contiguous range of logical indices (a bijection for any grid size).  PCL_TUNE_XCD=0 switches it off.
+__device__ __forceinline__ int xcd_logical_block(int on) {
+    if (!on) return blockIdx.x;
+    const int nb = gridDim.x, x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int base = nb >> 3, rem = nb & 7;
+    return x * base + (x < rem ? x : rem) + k;
+}
+
 // ---- unsplit algorithm without scratch planes (no capacity function) ---------------------------------
 // A workgroup of U_WAVES wavefronts takes U_WAVES consecutive slices (x phase: rows of one 64-cell
 // strip; y phase: columns of one 64-row strip).  Every wavefront computes its slice's pieces with the
@@ -580,7 +592,8 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, i
     __shared__ double gm[U_WAVES][MEQN][WAVE], gp[U_WAVES][MEQN][WAVE];
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = threadIdx.x / WAVE;
-    const int ta = blockIdx.x % nstrips, tr = blockIdx.x / nstrips;
+    const int bid = xcd_logical_block(a.xcd);
+    const int ta = bid % nstrips, tr = bid / nstrips;
     const int a0 = a.mbc - HALO + ta * STRIP;
     const int row = a.mbc - 1 + tr * U_OUT + w;        // slices j = 0 .. my+1  <->  rows mbc-1 .. mbc+my
     const bool slice_ok = row <= a.mbc + a.my;           // wave-uniform
@@ -622,7 +635,8 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
     constexpr int TP = U_WAVES + 1;
     __shared__ double tile[MEQN][WAVE][TP];
     __shared__ double gm[U_WAVES][MEQN][WAVE], gp[U_WAVES][MEQN][WAVE];
-    const int ti = blockIdx.x % ntiles_i, tj = blockIdx.x / ntiles_i;
+    const int bid = xcd_logical_block(a.xcd);
+    const int ti = bid % ntiles_i, tj = bid / ntiles_i;
     const int i0 = a.mbc - 1 + ti * U_OUT;               // slices i = 0 .. mx+1  <->  columns mbc-1 .. mbc+mx
     const int j0 = a.mbc - HALO + tj * STRIP;
     {   // cooperative load of qold: 16 lanes per row segment

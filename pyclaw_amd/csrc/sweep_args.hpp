@@ -27,6 +27,7 @@ struct SweepArgs {
     double dt, dx;    // separately, for the 1-D capa form dt/(dx*capa) (step1.f:70)
     RpParams par;
     unsigned long long *cfl;  // device word holding the running max (as ordered bits)
+    int xcd;          // XCD-aware block order in the kernels whose tiles share cache lines (classic.hpp)
     int ablate;       // diagnostic only (tools/kbench.py): bit0 = skip the arithmetic (copy through)
     // "virtual ghost cells": the x pass of the dim-split step evaluates the boundary conditions while it
     // loads (a ghost cell is an index remap of an interior cell, or a constant): no ghost-fill launches.
