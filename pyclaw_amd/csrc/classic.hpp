@@ -332,6 +332,18 @@ __device__ __forceinline__ VbcMap vbc_map(int k, int n, int mbc, int lo, int hi)
     return r;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2.  Tiles that share
+// cache lines (the unsplit kernels' 60-cell / 14-column pieces are not line-aligned) should therefore run on
+// the SAME XCD, close in time, so that the shared lines are fetched once and the two partial-line stores merge
+// in that L2 before they go to HBM.  This maps blockIdx to a logical index such that each XCD walks a
+// contiguous range of logical indices (a bijection for any grid size).  PCL_TUNE_XCD=0 switches it off.
+__device__ __forceinline__ int xcd_logical_block(int on) {
+    if (!on) return blockIdx.x;
+    const int nb = gridDim.x, x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int base = nb >> 3, rem = nb & 7;
+    return x * base + (x < rem ? x : rem) + k;
+}
+
 template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = false>
 __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     using T = TileShape<IXY>;
@@ -347,6 +359,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     // any moment stream whole rows.  (With the across index fastest in the x pass, all resident
     // workgroups read the same 2 KB column band of ~1000 rows whose pitch is 32 KB + 128 B: the
     // requests pile up on a few HBM channels and the pass drops to ~3.9 TB/s even as a pure copy.)
+    // (the XCD-aware order of xcd_logical_block was tried here too: x pass unchanged, y pass +8 % -- these tiles
+    // are line-aligned and share almost nothing)
     int tb = IXY == 1 ? blockIdx.x / ntiles_along : blockIdx.x % ntiles_across;
     int ta = IXY == 1 ? blockIdx.x % ntiles_along : blockIdx.x / ntiles_across;
     if (IXY == 1 && !DIM1 && !TRANS && a.sub != 0) {  // workgroup-uniform: interior box / its complement
@@ -563,18 +577,6 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
         }
     }
     cfl_publish(a.cfl, cflmax);
-}
-
-// Workgroups are handed to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2.  Tiles that share
-// cache lines (the unsplit kernels' 60-cell / 14-column pieces are not line-aligned) should therefore run on
-// the SAME XCD, close in time, so that the shared lines are fetched once and the two partial-line stores merge
-// in that L2 before they go to HBM.  This maps blockIdx to a logical index such that each XCD walks a
-// contiguous range of logical indices (a bijection for any grid size).  PCL_TUNE_XCD=0 switches it off.
-__device__ __forceinline__ int xcd_logical_block(int on) {
-    if (!on) return blockIdx.x;
-    const int nb = gridDim.x, x = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int base = nb >> 3, rem = nb & 7;
-    return x * base + (x < rem ? x : rem) + k;
 }
 
 // ---- unsplit algorithm without scratch planes (no capacity function) ---------------------------------
