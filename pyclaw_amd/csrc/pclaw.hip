@@ -1025,7 +1025,9 @@ int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, doubl
     if (!spare || !reg(A) || !reg(B) || !reg(D) || !s->sreg[PCL_REG_DQ])
         return fail(PCL_ESTATE, "pcl_sharp_stage: register not allocated (A=" + std::to_string(A) + " B=" + std::to_string(B) +
                                     " D=" + std::to_string(D) + ")");
-    if (int rc = sharp_passes(s, dt, op, reg(A), reg(B), spare, ca, cb, cc)) return rc;
+    // op 1 does not use B; the kernel still loads it (its store phase is branch-free, sharpclaw.hpp): point it at A
+    // so that the load hits the line A's load just brought in instead of streaming another array
+    if (int rc = sharp_passes(s, dt, op, reg(A), op == 1 ? reg(A) : reg(B), spare, ca, cb, cc)) return rc;
     if (int rc = read_cfl(s, cfl)) return rc;
     if (*cfl <= cfl_max) {
         std::swap(reg(D), s->sreg[PCL_REG_TMP]);

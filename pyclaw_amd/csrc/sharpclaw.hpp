@@ -110,15 +110,18 @@ __device__ __forceinline__ void weno5_legacy(double qm2, double qm1, double q0, 
 
 // ---- the kernel ----------------------------------------------------------------------------------
 // x pass (IXY=1): dq(interior) = dq1d ; y pass (IXY=2): dq += dq1d   (flux2.f90:54-56,86-88)
+// y pass: rows of 16 doubles with the column XOR-swizzled by (al >> 1): a wavefront reading one column (lanes =
+// rows) touches 32 distinct 8-byte banks per half-wave, a thread group reading a row touches 16 consecutive ones
+// -- conflict-free both ways without the 17th padding column, which keeps the tile at 40 KB (4 per CU).
 template <int IXY> __device__ __forceinline__ int stile_at(int m, int al, int ac) {
-    return IXY == 1 ? (m * T_ACROSS_S + ac) * WAVE + al : (m * WAVE + al) * (T_ACROSS_S + 1) + ac;
+    return IXY == 1 ? (m * T_ACROSS_S + ac) * WAVE + al : (m * WAVE + al) * T_ACROSS_S + (ac ^ ((al >> 1) & 15));
 }
 
 template <class RP, int IXY, bool CAPA, int LIM>
-__global__ __launch_bounds__(256) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
+__global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     constexpr int NP = MEQN + (CAPA ? 1 : 0);
-    constexpr int PLANE = IXY == 1 ? T_ACROSS_S * WAVE : WAVE * (T_ACROSS_S + 1);
+    constexpr int PLANE = T_ACROSS_S * WAVE;
     using Cell = typename RP::Cell;
     __shared__ double tile[NP * PLANE];
 
