@@ -215,3 +215,57 @@ def test_shockbubble_multi_tile_replay(coracle, device_callbacks):
     assert claw.solver.status['numsteps'] == st['numsteps'] and st['numsteps'] > 40
     assert claw.solver.status['cflmax'] == st['cflmax'] and claw.solver.status['dtmin'] == st['dtmin']
     assert np.array_equal(claw.frames[1].state.q, p.q)
+
+
+def test_fast_mode_other_kernel_families(coracle):
+    """The second arithmetic mode (FMA contraction + reciprocal-multiply division) through the kernels the
+    golden tests above do not reach: unsplit Euler (transverse solves), 3-D acoustics sweeps, SharpClaw Euler
+    (WENO5 + two Riemann solves, the occupancy-4 build with its spills) -- each within rtol 1e-12 of the
+    oracle after a short run (same step count: the dt history may differ in the last bits)."""
+    import pyclaw_amd as pyclaw
+    # unsplit Euler, 30 steps' worth
+    claw = problems.shockbubble(pyclaw, mx=200, my=60, tfinal=0.02, dim_split=False, order_trans=2, math='fast',
+                                dt_initial=0.004)
+    p = D.shockbubble_problem(mx=200, my=60, dim_split=False, order_trans=2)
+    p.dt_initial = 0.004
+    st = D.run(p, coracle, 0.02, 1)[-1]
+    assert claw.solver.status['numsteps'] == st['numsteps']
+    q = claw.frames[1].state.q
+    for m in range(5):
+        assert np.max(np.abs(q[m] - p.q[m])) < RTOL * np.abs(p.q[m]).max(), m
+    # 3-D acoustics, dim-split
+    claw = problems.acoustics3D(pyclaw, mx=40, my=12, mz=10, tfinal=0.2, nout=1, math='fast')
+    p = D.acoustics3d_problem('hom', mx=40, my=12, mz=10)
+    st = D.run(p, coracle, 0.2, 1)[-1]
+    assert claw.solver.status['numsteps'] == st['numsteps']
+    assert np.max(np.abs(claw.frames[1].state.q - p.q)) < RTOL * np.abs(p.q).max()
+    # SharpClaw Euler: one right-hand side through the C ABI
+    import ctypes as C
+    from pyclaw_amd import _lib as L
+    from oracle import oracle as O
+    rng = np.random.default_rng(2)
+    mx, my = 90, 70
+    q0 = np.empty((5, mx + 6, my + 6), order="F")
+    rho = 0.5 + rng.random(q0.shape[1:]); u = rng.random(q0.shape[1:]) - 0.5; v = rng.random(q0.shape[1:]) - 0.5
+    q0[0], q0[1], q0[2] = rho, rho * u, rho * v
+    q0[3] = (0.5 + rng.random(q0.shape[1:])) / 0.4 + 0.5 * rho * (u * u + v * v)
+    q0[4] = rng.random(q0.shape[1:])
+    ref, cfl_ref = coracle.sharp_flux2(O.RP_EULER5_2D, [1.4, 0.4], 2, 5, 0, 3, mx, my, q0, None, 0.01, 0.012, 1e-3)
+    cfg = L.Config()
+    cfg.ndim = 2; cfg.n[0], cfg.n[1] = mx, my; cfg.mbc = 3; cfg.meqn = cfg.mwaves = 5; cfg.rp = 11
+    cfg.method[1] = 2; cfg.rp_params[0], cfg.rp_params[1] = 1.4, 0.4
+    cfg.d[0], cfg.d[1] = 0.01, 0.012; cfg.kind = 1; cfg.lim_type = 2; cfg.math = 1
+    h = C.c_void_p()
+    L.check(L.lib().pcl_create(C.byref(cfg), C.byref(h)))
+    try:
+        L.check(L.lib().pcl_put_q(h, L.d(q0), 1))
+        cfl = C.c_double()
+        L.check(L.lib().pcl_sharp_dq(h, 1e-3, C.cast(C.byref(cfl), L.dp)))
+        L.check(L.lib().pcl_select(h, 3))
+        dq = np.zeros_like(q0)
+        L.check(L.lib().pcl_get_q(h, L.d(dq), 1))
+    finally:
+        L.lib().pcl_destroy(h)
+    inner = (slice(None), slice(3, -3), slice(3, -3))
+    assert abs(cfl.value - cfl_ref) < 1e-12 * cfl_ref
+    assert np.max(np.abs(dq[inner] - ref[inner])) < 1e-11 * np.abs(ref[inner]).max()
