@@ -52,6 +52,7 @@
 #define RP_SHALLOW_1D 5
 #define RP_ADVECTION_2D 12
 #define RP_SHALLOW_2D 13
+#define RP_VC_ACOUSTICS_2D 14
 #define RP_VC_ACOUSTICS_3D 20
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
@@ -390,6 +391,45 @@ static void rpt2_shallow(int ixy, int meqn, int mbc, int mx, const double *q, co
     }
 }
 
+/* The aux values of the slice being solved, for Riemann solvers with cell-wise coefficients: the Fortran passes
+ * aux2(:,:,2) of the slice next to q1d (flux2.f:99); the slice drivers below set these before every solve. */
+const double *orc_aux1d = NULL;    /* auxl: aux of the cell to the RIGHT of interface i is orc_aux1d(:, i)            */
+const double *orc_auxr1d = NULL;   /* auxr: aux of the cell to the LEFT is orc_auxr1d(:, i-1); NULL = same array        */
+int orc_maux1d = 0;
+
+/* 2-D acoustics with cell-wise impedance and sound speed, restated (third-party rpn2_vc_acoustics.f; same
+ * formulas as rpn3_vc_acoustics below); q = (p, u, v); aux(1) = Z, aux(2) = c */
+static void rpn2_vc_acoustics(int ixy, int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                              double *wave, double *s, double *amdq, double *apdq)
+{
+    const double *aux = orc_aux1d, *auxr = orc_auxr1d ? orc_auxr1d : orc_aux1d;
+    const int maux = orc_maux1d;
+#define AX(ma, i) aux[((ma)-1) + maux * IX(i)]
+#define AXR(ma, i) auxr[((ma)-1) + maux * IX(i)]
+    int mu = ixy + 1;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        double d1 = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        double d2 = A2(ql, mu, i) - A2(qr, mu, i - 1);
+        double zi = AX(1, i), zim = AXR(1, i - 1);
+        double a1 = (-d1 + zi * d2) / (zim + zi);
+        double a2 = (d1 + zim * d2) / (zim + zi);
+        for (int m = 1; m <= meqn; m++) { W(m, 1, i) = 0.0; W(m, 2, i) = 0.0; }
+        W(1, 1, i) = -a1 * zim;
+        W(mu, 1, i) = a1;
+        S(1, i) = -AXR(2, i - 1);
+        W(1, 2, i) = a2 * zi;
+        W(mu, 2, i) = a2;
+        S(2, i) = AX(2, i);
+    }
+    for (int m = 1; m <= meqn; m++)
+        for (int i = 2 - mbc; i <= mx + mbc; i++) {
+            A2(amdq, m, i) = S(1, i) * W(m, 1, i);
+            A2(apdq, m, i) = S(2, i) * W(m, 2, i);
+        }
+#undef AX
+#undef AXR
+}
+
 /* 2-D acoustics normal solver, restated (third-party rpn2_acoustics.f) */
 static void rpn2_acoustics(int ixy, int meqn, int mwaves, int mbc, int mx,
                            const double *ql, const double *qr, double *wave, double *s, double *amdq,
@@ -651,6 +691,10 @@ static int rpn2_dispatch(int rp, int ixy, int meqn, int mwaves, int mbc, int mx,
     case RP_SHALLOW_2D:
         rpn2_shallow(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
+    case RP_VC_ACOUSTICS_2D:
+        if (!orc_aux1d || orc_maux1d < 2) return -1;
+        rpn2_vc_acoustics(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
+        return 0;
     case RP_ACOUSTICS_2D:
         rpn2_acoustics(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
@@ -817,6 +861,9 @@ int orc_step2ds(int rp, const double *par, int fwave, int maxm, int meqn, int mw
     double cfl = 0.0, cfl1d;
     double dtdx = dt / dx, dtdy = dt / dy;
     int rc = 0;
+    double *aux1d = calloc((size_t)(maxm + 2 * mbc) * (maux > 0 ? maux : 1), sizeof(double));
+    orc_aux1d = aux1d;
+    orc_maux1d = maux;
 
     if (ids == 1) {
         if (mcapa == 0)
@@ -827,6 +874,8 @@ int orc_step2ds(int rp, const double *par, int fwave, int maxm, int meqn, int mw
             if (mcapa > 0)
                 for (int i = 1 - mbc; i <= mx + mbc; i++)
                     dtdx1d[IX(i)] = dtdx / AUX3(mcapa, i, j);
+            for (int i = 1 - mbc; i <= mx + mbc; i++)
+                for (int ma = 1; ma <= maux; ma++) aux1d[(ma - 1) + maux * IX(i)] = AUX3(ma, i, j);
             rc |= flux2(rp, par, fwave, 1, meqn, mwaves, mbc, mx, method, mthlim, &w, &cfl1d);
             cfl = dmax(cfl, cfl1d);
             if (mcapa == 0) {
@@ -851,6 +900,8 @@ int orc_step2ds(int rp, const double *par, int fwave, int maxm, int meqn, int mw
             if (mcapa > 0)
                 for (int j = 1 - mbc; j <= my + mbc; j++)
                     dtdx1d[IX(j)] = dtdy / AUX3(mcapa, i, j);
+            for (int j = 1 - mbc; j <= my + mbc; j++)
+                for (int ma = 1; ma <= maux; ma++) aux1d[(ma - 1) + maux * IX(j)] = AUX3(ma, i, j);
             rc |= flux2(rp, par, fwave, 2, meqn, mwaves, mbc, my, method, mthlim, &w, &cfl1d);
             cfl = dmax(cfl, cfl1d);
             if (mcapa == 0) {
@@ -868,6 +919,8 @@ int orc_step2ds(int rp, const double *par, int fwave, int maxm, int meqn, int mw
         }
     }
     *cfl_out = cfl;
+    orc_aux1d = NULL;
+    free(aux1d);
     work_free(&w);
     return rc;
 }

@@ -29,6 +29,7 @@ RP_SHALLOW_1D = 5
 RP_ACOUSTICS_2D = 10
 RP_ADVECTION_2D = 12
 RP_SHALLOW_2D = 13
+RP_VC_ACOUSTICS_2D = 14
 RP_EULER5_2D = 11
 RP_VC_ACOUSTICS_3D = 20
 

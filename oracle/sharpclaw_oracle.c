@@ -146,8 +146,23 @@ static int flux1(int ndim, int rp, const double *par, int lim_type, int ixy, int
             qr[m + meqn * IX(i - 1)] = ql[m + meqn * IX(i)];
             ql[m + meqn * IX(i)] = qr[m + meqn * IX(i)];
         }
-    if (ndim == 1) rc = orc_rp1_ptr(rp, par, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq2, apdq2);
-    else rc = orc_rpn2_ptr(rp, par, ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq2, apdq2);
+    /* flux1.f90:173-178: auxr(:,i-1) = aux(:,i), auxl(:,i) = aux(:,i): both edge states of cell i see its own aux */
+    {
+        extern const double *orc_aux1d, *orc_auxr1d;
+        extern int orc_maux1d;
+        double *auxr = NULL;
+        if (orc_aux1d && orc_maux1d > 0) {
+            auxr = calloc((size_t)orc_maux1d * n, sizeof(double));
+            for (int i = 1 - mbc + 1; i <= mx + mbc; i++)
+                for (int ma = 0; ma < orc_maux1d; ma++)
+                    auxr[ma + orc_maux1d * IX(i - 1)] = orc_aux1d[ma + orc_maux1d * IX(i)];
+            orc_auxr1d = auxr;
+        }
+        if (ndim == 1) rc = orc_rp1_ptr(rp, par, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq2, apdq2);
+        else rc = orc_rpn2_ptr(rp, par, ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq2, apdq2);
+        orc_auxr1d = NULL;
+        free(auxr);
+    }
     if (rc) return rc;
     for (int i = 1; i <= mx; i++)
         for (int m = 0; m < meqn; m++)
@@ -170,6 +185,11 @@ int orc_sharp_flux2(int rp, const double *par, int lim_type, int meqn, int mwave
     double *work = calloc((size_t)meqn * nmax * 6 + (size_t)meqn * mwaves * nmax + (size_t)mwaves * nmax, sizeof(double));
     double cfl = 0.0, cfl1d;
     int rc = 0;
+    extern const double *orc_aux1d;
+    extern int orc_maux1d;
+    double *aux1d = calloc((size_t)nmax * (maux > 0 ? maux : 1), sizeof(double));
+    orc_aux1d = aux1d;
+    orc_maux1d = maux;
     memset(dq, 0, sizeof(double) * (size_t)meqn * I * J);
 #define G(m, i, j) ((m) + (size_t)meqn * (((i) + mbc - 1) + (size_t)I * ((j) + mbc - 1)))
 #define A(ma, i, j) aux[((ma)-1) + (size_t)maux * (((i) + mbc - 1) + (size_t)I * ((j) + mbc - 1))]
@@ -177,6 +197,7 @@ int orc_sharp_flux2(int rp, const double *par, int lim_type, int meqn, int mwave
         for (int i = 1 - mbc; i <= mx + mbc; i++) {
             for (int m = 0; m < meqn; m++) q1d[m + meqn * (i + mbc - 1)] = q[G(m, i, j)];
             dtdx[i + mbc - 1] = (mcapa > 0) ? dt / (dx * A(mcapa, i, j)) : dt / dx;
+            for (int ma = 1; ma <= maux; ma++) aux1d[(ma - 1) + maux * (i + mbc - 1)] = A(ma, i, j);
         }
         memset(dq1d, 0, sizeof(double) * (size_t)meqn * nmax);
         rc = flux1(2, rp, par, lim_type, 1, meqn, mwaves, mbc, mx, q1d, dq1d, dtdx, &cfl1d, work);
@@ -188,6 +209,7 @@ int orc_sharp_flux2(int rp, const double *par, int lim_type, int meqn, int mwave
         for (int j = 1 - mbc; j <= my + mbc; j++) {
             for (int m = 0; m < meqn; m++) q1d[m + meqn * (j + mbc - 1)] = q[G(m, i, j)];
             dtdx[j + mbc - 1] = (mcapa > 0) ? dt / (dy * A(mcapa, i, j)) : dt / dy;
+            for (int ma = 1; ma <= maux; ma++) aux1d[(ma - 1) + maux * (j + mbc - 1)] = A(ma, i, j);
         }
         memset(dq1d, 0, sizeof(double) * (size_t)meqn * nmax);
         rc = flux1(2, rp, par, lim_type, 2, meqn, mwaves, mbc, my, q1d, dq1d, dtdx, &cfl1d, work);
@@ -196,6 +218,8 @@ int orc_sharp_flux2(int rp, const double *par, int lim_type, int meqn, int mwave
             for (int m = 0; m < meqn; m++) dq[G(m, i, j)] = dq[G(m, i, j)] + dq1d[m + meqn * (j + mbc - 1)];
     }
     *cfl_out = cfl;
+    orc_aux1d = NULL;
+    free(aux1d);
     free(q1d); free(dq1d); free(dtdx); free(work);
     return rc;
 }

@@ -348,7 +348,10 @@ template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = fals
 __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     using T = TileShape<IXY>;
     constexpr int MEQN = RP::MEQN;
-    constexpr int NP = MEQN + (CAPA ? 1 : 0);
+    // tile planes: q(0..MEQN-1), the capacity function (CAPA), then the first RP::NAUX aux components for
+    // Riemann solvers with cell-wise coefficients (variable-coefficient problems)
+    constexpr int NAUX = RP::NAUX, PAUX = MEQN + (CAPA ? 1 : 0);
+    constexpr int NP = PAUX + NAUX;
     __shared__ double tile[NP * T::PLANE];
 
     // extents of the swept (along) and transverse (across) directions, ghost cells included
@@ -411,6 +414,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
 #pragma unroll
                     for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = a.qin[m * a.plane + g];
                     if constexpr (CAPA) tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
+#pragma unroll
+                    for (int m = 0; m < NAUX; m++) tile[T::at(PAUX + m, al, ac)] = a.aux[m * a.plane + g];
                 }
             } else {
                 // qbc = Y(X(q)): x sides first, then y sides over the x-filled array (solver.py:354-381)
@@ -436,6 +441,9 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
                     }
                     if constexpr (CAPA)
                         tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + (long)gb * a.pitch + ga];
+#pragma unroll
+                    for (int m = 0; m < NAUX; m++)   // aux ghost cells are real memory (auxbc is filled once at setup)
+                        tile[T::at(PAUX + m, al, ac)] = a.aux[m * a.plane + (long)gb * a.pitch + ga];
                 }
             }
         }
@@ -452,6 +460,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
 #pragma unroll
             for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = a.qin[m * a.plane + g];
             if constexpr (CAPA) tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
+#pragma unroll
+            for (int m = 0; m < NAUX; m++) tile[T::at(PAUX + m, al, ac)] = a.aux[m * a.plane + g];
         }
     }
     __syncthreads();
@@ -500,11 +510,14 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             if constexpr (CAPA) capanext = tile[T::at(MEQN, unit_al(u + 1), unit_ac(u + 1))];
         }
         if constexpr (CAPA) dtdx_c = DIM1 ? a.dt / (a.dx * capa) : a.dtd / capa;
+        double auxv[NAUX > 0 ? NAUX : 1];
+#pragma unroll
+        for (int m = 0; m < NAUX; m++) auxv[m] = tile[T::at(PAUX + m, al, ac)];   // aux planes are never overwritten
         if constexpr (TRANS) {
             // unsplit algorithm: this slice's pieces for the cell go to scratch planes; they are
             // summed into qnew in the reference's order by combine_kernel (step2.f:130-137,214-218)
             double df[MEQN], g1[MEQN], g2[MEQN];
-            lane_core<RP, IXY, CAPA, FWAVE, DIM1, true>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, df, g1, g2);
+            lane_core<RP, IXY, CAPA, FWAVE, DIM1, true>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, df, g1, g2, auxv);
             if (owned) {
                 const int gb = b0 + ac;
                 const long g = IXY == 1 ? (long)gb * a.pitch + ca : (long)ca * a.pitch + gb;
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) qn[m] = q[m];
             } else
-                lane_core<RP, IXY, CAPA, FWAVE, DIM1>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax);
+                lane_core<RP, IXY, CAPA, FWAVE, DIM1>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, nullptr, nullptr, nullptr, auxv);
             if (owned) {
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = qn[m];

@@ -515,6 +515,7 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     case PCL_RP_SHALLOW_1D: want_meqn = 2; want_mwaves = 2; want_ndim = 1; break;
     case PCL_RP_ADVECTION_2D: want_meqn = 1; want_mwaves = 1; want_ndim = 2; break;
     case PCL_RP_SHALLOW_2D: want_meqn = 3; want_mwaves = 3; want_ndim = 2; break;
+    case PCL_RP_VC_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
     case PCL_RP_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
     case PCL_RP_EULER5_2D: want_meqn = 5; want_mwaves = 5; want_ndim = 2; break;
     case PCL_RP_VC_ACOUSTICS_3D: want_meqn = 4; want_mwaves = 2; want_ndim = 3; break;
@@ -525,6 +526,11 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     for (int d = 0; d < cfg->ndim; d++)
         if (cfg->n[d] < 1) return fail(PCL_EINVAL, "grid extent must be >= 1");
     if (cfg->method[5] < 0 || cfg->method[5] > cfg->maux) return fail(PCL_EINVAL, "mcapa out of range");
+    if (cfg->rp == PCL_RP_VC_ACOUSTICS_2D) {
+        if (cfg->maux < 2) return fail(PCL_EINVAL, "rpn2_vc_acoustics needs aux(1)=impedance, aux(2)=sound speed");
+        if (cfg->kind == PCL_KIND_CLASSIC && cfg->method[2] >= 0)
+            return fail(PCL_EINVAL, "rpn2_vc_acoustics: dim_split=True only (rpt2_vc_acoustics is not built)");
+    }
     if (cfg->ndim == 3) {
         if (cfg->kind != PCL_KIND_CLASSIC) return fail(PCL_EINVAL, "3-D: classic solver only (the reference has no 3-D SharpClaw)");
         if (cfg->maux < 2) return fail(PCL_EINVAL, "rpn3_vc_acoustics needs aux(1)=impedance, aux(2)=sound speed");

@@ -409,6 +409,46 @@ struct Acoustics2D {
     }
 };
 
+// ---- 2-D acoustics with cell-wise impedance and sound speed (third-party rpn2_vc_acoustics.f, restated: the
+// formulas of VcAcoustics3D below); q = (p, u, v); aux(1) = Z, aux(2) = c.  No transverse solver here:
+// rpt2_vc_acoustics needs the aux values of the neighbouring rows -- dimension-split and SharpClaw only.
+struct VcAcoustics2D {
+    static constexpr int MEQN = 3, MWAVES = 2, NAUX = 2;
+    struct Cell { double q[3]; double z, c; };
+    template <int IXY> __device__ static constexpr bool nz(int /*mw*/, int m) { return m == 0 || m == IXY; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &, const double *auxv) {
+        Cell c;
+        for (int m = 0; m < 3; m++) c.q[m] = q[m];
+        c.z = auxv[0];
+        c.c = auxv[1];
+        return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &,
+                                                 double (&wave)[2][3], double (&s)[2], double (&amdq)[3],
+                                                 double (&apdq)[3]) {
+        constexpr int mu = IXY;
+        const double d1 = R.q[0] - L.q[0];
+        const double d2 = R.q[mu] - L.q[mu];
+        const double zi = R.z, zim = L.z;
+        const Recip by_zz(zim + zi);
+        const double a1 = by_zz.div(-d1 + zi * d2);
+        const double a2 = by_zz.div(d1 + zim * d2);
+        for (int m = 0; m < 3; m++) { wave[0][m] = 0.0; wave[1][m] = 0.0; }
+        wave[0][0] = -a1 * zim; wave[0][mu] = a1; s[0] = -L.c;
+        wave[1][0] = a2 * zi;   wave[1][mu] = a2; s[1] = R.c;
+        for (int m = 0; m < 3; m++) {
+            amdq[m] = nz<IXY>(0, m) ? s[0] * wave[0][m] : 0.0;
+            apdq[m] = nz<IXY>(1, m) ? s[1] * wave[1][m] : 0.0;
+        }
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &, double (&s)[2]) {
+        s[0] = -L.c; s[1] = R.c;
+    }
+};
+
 // ---- 3-D acoustics with cell-wise impedance and sound speed (third-party rpn3_vc_acoustics.f, restated;
 // named by the reference's test/acoustics/3d/Makefile) --------------------------------------------------
 // q = (p, u, v, w); aux(1) = Z, aux(2) = c.  DIR = 1,2,3 selects the normal velocity q(DIR).

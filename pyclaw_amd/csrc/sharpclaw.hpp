@@ -120,7 +120,8 @@ template <int IXY> __device__ __forceinline__ int stile_at(int m, int al, int ac
 template <class RP, int IXY, bool CAPA, int LIM>
 __global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
-    constexpr int NP = MEQN + (CAPA ? 1 : 0);
+    constexpr int NAUX = RP::NAUX, PAUX = MEQN + (CAPA ? 1 : 0);   // planes: q, capa, the RP's aux components
+    constexpr int NP = PAUX + NAUX;
     constexpr int PLANE = T_ACROSS_S * WAVE;
     using Cell = typename RP::Cell;
     __shared__ double tile[NP * PLANE];
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, i
 #pragma unroll
         for (int m = 0; m < MEQN; m++) tile[stile_at<IXY>(m, al, ac)] = a.qin[m * a.plane + g];
         if constexpr (CAPA) tile[stile_at<IXY>(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
+#pragma unroll
+        for (int m = 0; m < NAUX; m++) tile[stile_at<IXY>(PAUX + m, al, ac)] = a.aux[m * a.plane + g];
     }
     __syncthreads();
 
@@ -180,8 +183,18 @@ __global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, i
         if constexpr (CAPA) dtdx_c = a.dt / (a.dx * tile[stile_at<IXY>(MEQN, lane, ac)]);  // flux1.f90:60
         const double dtdx_l = CAPA ? from_left(dtdx_c) : dtdx_c;
 
-        const Cell cl = RP::template precell<IXY>(ql, a.par);   // left-edge state of this cell
-        const Cell cr = RP::template precell<IXY>(qr, a.par);   // right-edge state of this cell
+        // both edge states carry the cell's own aux values (flux1.f90:125 passes aux,aux)
+        double auxv[NAUX > 0 ? NAUX : 1];
+#pragma unroll
+        for (int m = 0; m < NAUX; m++) auxv[m] = tile[stile_at<IXY>(PAUX + m, lane, ac)];
+        Cell cl, cr;
+        if constexpr (NAUX > 0) {
+            cl = RP::template precell<IXY>(ql, a.par, auxv);
+            cr = RP::template precell<IXY>(qr, a.par, auxv);
+        } else {
+            cl = RP::template precell<IXY>(ql, a.par);   // left-edge state of this cell
+            cr = RP::template precell<IXY>(qr, a.par);   // right-edge state of this cell
+        }
         const Cell crl = struct_from_left(cr);                  // right-edge state of cell i-1
         double wave[MWAVES][MEQN], s[MWAVES], amdq[MEQN], apdq[MEQN], amdq2[MEQN], apdq2[MEQN];
         RP::template solve<IXY>(crl, cl, a.par, wave, s, amdq, apdq);       // interface i   (flux1.f90:125)

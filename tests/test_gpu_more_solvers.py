@@ -309,3 +309,59 @@ def test_radial_dam_break_app():
     r = np.sqrt(X ** 2 + Y ** 2)
     assert h[r < 0.3].mean() < 1.5 and h[(r > 1.2) & (r < 1.6)].max() > 1.05      # centre dropped, bore outside
     assert np.isfinite(claw.frames[1].state.q).all()
+
+
+@pytest.mark.parametrize("shape", [(10, 7), (130, 90)])
+@pytest.mark.parametrize("lims", [[4, 4], [1, 0]])
+def test_vc_acoustics2d_split_and_sharpclaw(coracle, shape, lims):
+    """Riemann solver with cell-wise coefficients: the kernels stage the solver's aux components next to q in
+    the LDS tile (classic dim-split x/y, SharpClaw with and without a capacity function in a third aux field)."""
+    from pyclaw_amd import _lib as L
+    mx, my = shape
+    rng = np.random.default_rng(mx + lims[0])
+    cfl = C.c_double()
+    mth = np.array(lims, dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.1 / max(mx, my)
+    q0 = np.asfortranarray(rng.standard_normal((3, mx + 4, my + 4)))
+    aux = np.asfortranarray(0.5 + 2.0 * rng.random((2, mx + 4, my + 4)))
+    method = np.array([1, 2, -1, 0, 0, 0, 2], dtype=np.int32)
+    for ids in (1, 2):
+        ref = q0.copy("F")
+        _, cfl_ref = coracle.step2ds(O.RP_VC_ACOUSTICS_2D, [0.0], max(mx, my), 2, mx, my, q0.copy("F"), ref, aux, dx, dy,
+                                     dt, method, mth, ids)
+        out = q0.copy("F")
+        L.check(L.lib().pcl_step2ds(O.RP_VC_ACOUSTICS_2D, None, 0, 3, 2, 2, 2, mx, my, L.d(q0), L.d(out), L.d(aux), dx,
+                                    dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp), ids))
+        assert np.array_equal(out, ref) and cfl.value == cfl_ref and cfl.value > 0
+    for mcapa, maux in ((0, 2), (3, 3)):
+        q3 = np.asfortranarray(rng.standard_normal((3, mx + 6, my + 6)))
+        a3 = np.asfortranarray(0.5 + 2.0 * rng.random((maux, mx + 6, my + 6)))
+        ref, cfl_ref = coracle.sharp_flux2(O.RP_VC_ACOUSTICS_2D, [0.0], 2, 2, mcapa, 3, mx, my, q3, a3, dx, dy, dt)
+        dq = np.zeros_like(q3)
+        L.check(L.lib().pcl_sharp_flux2(O.RP_VC_ACOUSTICS_2D, None, 2, 3, 2, maux, mcapa, 3, mx, my, L.d(q3), L.d(dq),
+                                        L.d(a3), dx, dy, dt, C.cast(C.byref(cfl), L.dp)))
+        assert np.array_equal(dq[:, 3:-3, 3:-3], ref[:, 3:-3, 3:-3]) and cfl.value == cfl_ref
+
+
+def test_vc_acoustics2d_uniform_medium_equals_constant_coefficient_golden(golden_dir):
+    """With a uniform medium the variable-coefficient solver must do exactly what rpn2_acoustics does: the 2-D
+    acoustics regression (test/test_examples.py:239-254) run with rp_vc_acoustics_2d + aux = (zz, cc) equals the
+    constant-coefficient run bit for bit -- and so inherits its pin, the reference golden acoustics2D_solution."""
+    import os
+    import pyclaw_amd as pyclaw
+    from apps import problems
+    const = problems.acoustics2D(pyclaw)
+    claw = problems.acoustics2D(pyclaw, run=False)
+    old = claw.solution.state
+    state = pyclaw.State(old.grid, 3, 2)
+    state.q[...] = old.q
+    state.aux[0] = old.aux_global['zz']
+    state.aux[1] = old.aux_global['cc']
+    claw.solution = pyclaw.Solution(state)
+    claw.solver.rp = pyclaw.riemann.rp_vc_acoustics_2d
+    for k in range(2):
+        claw.solver.aux_bc_lower[k] = claw.solver.aux_bc_upper[k] = pyclaw.BC.outflow
+    claw.run()
+    assert np.array_equal(claw.frames[claw.nout].state.q, const.frames[const.nout].state.q)
+    gold = np.loadtxt(os.path.join(golden_dir, "acoustics2D_solution"))
+    assert np.linalg.norm(claw.frames[claw.nout].state.q[0] - gold) < 2e-14
