@@ -52,6 +52,7 @@ extern "C" {
 #define PCL_RP_BURGERS_1D 3     /* rp1_burgers.f90 (transonic entropy fix); no cparam            */
 #define PCL_RP_EULER_1D 4       /* rp1_euler_with_efix.f          cparam: gamma,gamma1            */
 #define PCL_RP_SHALLOW_1D 5     /* rp1_shallow_roe_with_efix.f    cparam: g                       */
+#define PCL_RP_ADVECTION_COLOR_1D 6 /* rp1_advection_color.f; aux(1) = velocity at the cell's left edge */
 #define PCL_RP_ACOUSTICS_2D 10 /* rpn2/rpt2_acoustics.f     cparam: rho,bulk,cc,zz      */
 #define PCL_RP_EULER5_2D 11    /* rpn2/rpt2_euler_5wave.f   cparam: gamma,gamma1        */
 #define PCL_RP_ADVECTION_2D 12  /* rpn2/rpt2_advection.f      cparam: u,v                  */

@@ -50,6 +50,7 @@
 #define RP_BURGERS_1D 3
 #define RP_EULER_1D 4
 #define RP_SHALLOW_1D 5
+#define RP_ADVECTION_COLOR_1D 6
 #define RP_ADVECTION_2D 12
 #define RP_SHALLOW_2D 13
 #define RP_VC_ACOUSTICS_2D 14
@@ -164,6 +165,22 @@ static void rp1_burgers(int meqn, int mwaves, int mbc, int mx, const double *ql,
             A2(amdq, 1, i) = -0.5 * (qL * qL);
             A2(apdq, 1, i) = 0.5 * (qR * qR);
         }
+    }
+}
+
+/* 1-D colour equation q_t + u(x) q_x = 0, restated (third-party rp1_advection_color.f, apps/advection/1d/variable):
+ * aux(1,i) = velocity at the LEFT edge of cell i, i.e. at interface i */
+extern const double *orc_aux1d;
+extern int orc_maux1d;
+static void rp1_advection_color(int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                                double *wave, double *s, double *amdq, double *apdq)
+{
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const double u = orc_aux1d[0 + orc_maux1d * IX(i)];
+        W(1, 1, i) = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        S(1, i) = u;
+        A2(amdq, 1, i) = dmin(u, 0.0) * W(1, 1, i);
+        A2(apdq, 1, i) = dmax(u, 0.0) * W(1, 1, i);
     }
 }
 
@@ -1044,6 +1061,11 @@ int orc_step1(int rp, const double *par, int meqn, int mwaves, int maux, int mbc
     case RP_BURGERS_1D: rp1_burgers(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
     case RP_EULER_1D: rp1_euler(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
     case RP_SHALLOW_1D: rp1_shallow(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq, par); break;
+    case RP_ADVECTION_COLOR_1D:
+        orc_aux1d = aux; orc_maux1d = maux;       /* step1.f:78: rp1(..., q, q, aux, aux, ...) */
+        rp1_advection_color(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq);
+        orc_aux1d = NULL;
+        break;
     default: rc = -1;
     }
     if (!rc) {
@@ -1101,6 +1123,10 @@ int orc_rp1_ptr(int rp, const double *par, int meqn, int mwaves, int mbc, int mx
     case RP_BURGERS_1D: rp1_burgers(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
     case RP_EULER_1D: rp1_euler(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
     case RP_SHALLOW_1D: rp1_shallow(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par); return 0;
+    case RP_ADVECTION_COLOR_1D:
+        if (!orc_aux1d || orc_maux1d < 1) return -1;
+        rp1_advection_color(meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
+        return 0;
     }
     return -1;
 }

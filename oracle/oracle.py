@@ -26,6 +26,7 @@ RP_ACOUSTICS_1D = 2
 RP_BURGERS_1D = 3
 RP_EULER_1D = 4
 RP_SHALLOW_1D = 5
+RP_ADVECTION_COLOR_1D = 6
 RP_ACOUSTICS_2D = 10
 RP_ADVECTION_2D = 12
 RP_SHALLOW_2D = 13

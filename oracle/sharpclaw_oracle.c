@@ -235,7 +235,12 @@ int orc_sharp_flux1(int rp, const double *par, int lim_type, int meqn, int mwave
     for (int i = 0; i < n; i++)
         dtdx[i] = (mcapa > 0) ? dt / (dx * aux[(mcapa - 1) + (size_t)maux * i]) : dt / dx;
     memset(dq, 0, sizeof(double) * (size_t)meqn * n);   /* f2py zero-fills the optional dq1d */
+    extern const double *orc_aux1d;
+    extern int orc_maux1d;
+    orc_aux1d = (maux > 0) ? aux : NULL;     /* 1-D: the aux array is the slice */
+    orc_maux1d = maux;
     int rc = flux1(1, rp, par, lim_type, 1, meqn, mwaves, mbc, mx, q, dq, dtdx, cfl_out, work);
+    orc_aux1d = NULL;
     free(dtdx); free(work);
     return rc;
 }

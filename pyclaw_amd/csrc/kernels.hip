@@ -64,6 +64,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_BURGERS_1D) return launch<Burgers1D, 1, true>(l, err);
         if (rp == PCL_RP_EULER_1D) return launch<Euler1D, 1, true>(l, err);
         if (rp == PCL_RP_SHALLOW_1D) return launch<Shallow1D, 1, true>(l, err);
+        if (rp == PCL_RP_ADVECTION_COLOR_1D) return launch<AdvectionColor1D, 1, true>(l, err);
         err = "Riemann solver id is not a 1-D solver";
         return PCL_EINVAL;
     }
@@ -216,6 +217,7 @@ int launch_sharp(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_BURGERS_1D) return launch_sharp_t<Burgers1D, 1>(l, err);
         if (rp == PCL_RP_EULER_1D) return launch_sharp_t<Euler1D, 1>(l, err);
         if (rp == PCL_RP_SHALLOW_1D) return launch_sharp_t<Shallow1D, 1>(l, err);
+        if (rp == PCL_RP_ADVECTION_COLOR_1D) return launch_sharp_t<AdvectionColor1D, 1>(l, err);
     } else if (l.ids == 1) {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 1>(l, err);
         if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 1>(l, err);

@@ -513,6 +513,7 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     case PCL_RP_BURGERS_1D: want_meqn = 1; want_mwaves = 1; want_ndim = 1; break;
     case PCL_RP_EULER_1D: want_meqn = 3; want_mwaves = 3; want_ndim = 1; break;
     case PCL_RP_SHALLOW_1D: want_meqn = 2; want_mwaves = 2; want_ndim = 1; break;
+    case PCL_RP_ADVECTION_COLOR_1D: want_meqn = 1; want_mwaves = 1; want_ndim = 1; break;
     case PCL_RP_ADVECTION_2D: want_meqn = 1; want_mwaves = 1; want_ndim = 2; break;
     case PCL_RP_SHALLOW_2D: want_meqn = 3; want_mwaves = 3; want_ndim = 2; break;
     case PCL_RP_VC_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
@@ -526,6 +527,8 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     for (int d = 0; d < cfg->ndim; d++)
         if (cfg->n[d] < 1) return fail(PCL_EINVAL, "grid extent must be >= 1");
     if (cfg->method[5] < 0 || cfg->method[5] > cfg->maux) return fail(PCL_EINVAL, "mcapa out of range");
+    if (cfg->rp == PCL_RP_ADVECTION_COLOR_1D && cfg->maux < 1)
+        return fail(PCL_EINVAL, "rp1_advection_color needs aux(1) = edge velocity");
     if (cfg->rp == PCL_RP_VC_ACOUSTICS_2D) {
         if (cfg->maux < 2) return fail(PCL_EINVAL, "rpn2_vc_acoustics needs aux(1)=impedance, aux(2)=sound speed");
         if (cfg->kind == PCL_KIND_CLASSIC && cfg->method[2] >= 0)

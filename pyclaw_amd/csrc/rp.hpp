@@ -125,6 +125,33 @@ struct Advection1D {
 };
 
 // ------------------------------------------------------------------------------------
+// 1-D colour equation q_t + u(x) q_x = 0 (third-party rp1_advection_color.f, restated): aux(1) of a cell is the
+// velocity at its LEFT edge, so interface i uses the right cell's value
+// ------------------------------------------------------------------------------------
+struct AdvectionColor1D {
+    static constexpr int MEQN = 1, MWAVES = 1, NCELL = 2, NAUX = 1;
+    struct Cell { double q[1]; double u; };
+    template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &, const double *auxv) {
+        Cell c; c.q[0] = q[0]; c.u = auxv[0]; return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &,
+                                                 double (&wave)[1][1], double (&s)[1],
+                                                 double (&amdq)[1], double (&apdq)[1]) {
+        wave[0][0] = R.q[0] - L.q[0];
+        s[0] = R.u;
+        amdq[0] = dmin(R.u, 0.0) * wave[0][0];
+        apdq[0] = dmax(R.u, 0.0) * wave[0][0];
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &, const Cell &R, const RpParams &, double (&s)[1]) {
+        s[0] = R.u;
+    }
+};
+
+// ------------------------------------------------------------------------------------
 // 1-D Burgers' equation with the transonic entropy fix (third-party rp1_burgers.f90, restated)
 // ------------------------------------------------------------------------------------
 struct Burgers1D {

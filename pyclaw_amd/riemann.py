@@ -33,6 +33,7 @@ class RiemannSolver(object):
 
 rp_advection_1d = RiemannSolver("advection_1d", 1, 1, 1, 1, ["u"])
 rp_acoustics_1d = RiemannSolver("acoustics_1d", 2, 1, 2, 2, ["rho", "bulk", "cc", "zz"])
+rp_advection_color_1d = RiemannSolver("advection_color_1d", 6, 1, 1, 1, [])        # aux(1) = velocity at the left edge
 rp_burgers_1d = RiemannSolver("burgers_1d", 3, 1, 1, 1, [])
 rp_euler_1d = RiemannSolver("euler_1d", 4, 1, 3, 3, ["gamma", "gamma1"])            # rp1_euler_with_efix
 rp_shallow_1d = RiemannSolver("shallow_1d", 5, 1, 2, 2, ["g"])                       # rp1_shallow_roe_with_efix
@@ -46,7 +47,7 @@ rp_euler_5wave_2d = RiemannSolver("euler_5wave_2d", 11, 2, 5, 5, ["gamma", "gamm
 # rpn3_vc_acoustics.f; the transverse rpt3/rptt3 of the unsplit algorithm are not built: dim_split only)
 rp_vc_acoustics_3d = RiemannSolver("vc_acoustics_3d", 20, 3, 4, 2, [])
 
-_ALL = [rp_advection_1d, rp_acoustics_1d, rp_burgers_1d, rp_euler_1d, rp_shallow_1d, rp_advection_2d, rp_shallow_2d, rp_vc_acoustics_2d, rp_acoustics_2d, rp_euler_5wave_2d, rp_vc_acoustics_3d]
+_ALL = [rp_advection_1d, rp_acoustics_1d, rp_advection_color_1d, rp_burgers_1d, rp_euler_1d, rp_shallow_1d, rp_advection_2d, rp_shallow_2d, rp_vc_acoustics_2d, rp_acoustics_2d, rp_euler_5wave_2d, rp_vc_acoustics_3d]
 BY_NAME = dict((r.name, r) for r in _ALL)
 
 

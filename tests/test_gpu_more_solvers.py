@@ -365,3 +365,29 @@ def test_vc_acoustics2d_uniform_medium_equals_constant_coefficient_golden(golden
     assert np.array_equal(claw.frames[claw.nout].state.q, const.frames[const.nout].state.q)
     gold = np.loadtxt(os.path.join(golden_dir, "acoustics2D_solution"))
     assert np.linalg.norm(claw.frames[claw.nout].state.q[0] - gold) < 2e-14
+
+
+@pytest.mark.parametrize("mx", [40, 301])
+def test_advection_color_1d(coracle, mx):
+    """rp1_advection_color: velocity per cell edge in aux(1) -- the 1-D kernels with a solver aux plane."""
+    from pyclaw_amd import _lib as L
+    rng = np.random.default_rng(mx)
+    method = np.array([1, 2, 0, 0, 0, 0, 1], dtype=np.int32)
+    mth = np.array([3], dtype=np.int32)
+    dx, dt = 1.0 / mx, 0.3 / mx
+    q = np.asfortranarray(rng.random((1, mx + 4)))
+    aux = np.asfortranarray(1.5 * (rng.random((1, mx + 4)) - 0.3))          # both signs
+    ref = q.copy("F")
+    _, cfl_ref = coracle.step1(O.RP_ADVECTION_COLOR_1D, [0.0], 2, mx, ref, aux, dx, dt, method, mth)
+    out = q.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step1(O.RP_ADVECTION_COLOR_1D, None, 1, 1, 1, 2, mx, L.d(out), L.d(aux), dx, dt, L.i(method),
+                              L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    assert np.array_equal(out[:, 2:-2], ref[:, 2:-2]) and cfl.value == cfl_ref and cfl.value > 0
+    q3 = np.asfortranarray(rng.random((1, mx + 6)))
+    a3 = np.asfortranarray(1.5 * (rng.random((1, mx + 6)) - 0.3))
+    ref, cfl_ref = coracle.sharp_flux1(O.RP_ADVECTION_COLOR_1D, [0.0], 2, 1, 0, 3, mx, q3, a3, dx, dt)
+    dq = np.zeros_like(q3)
+    L.check(L.lib().pcl_sharp_flux1(O.RP_ADVECTION_COLOR_1D, None, 2, 1, 1, 1, 0, 3, mx, L.d(q3), L.d(dq), L.d(a3), dx,
+                                    dt, C.cast(C.byref(cfl), L.dp)))
+    assert np.array_equal(dq[:, 3:-3], ref[:, 3:-3]) and cfl.value == cfl_ref
