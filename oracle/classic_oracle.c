@@ -413,6 +413,8 @@ static void rpt2_shallow(int ixy, int meqn, int mbc, int mx, const double *q, co
 const double *orc_aux1d = NULL;    /* auxl: aux of the cell to the RIGHT of interface i is orc_aux1d(:, i)            */
 const double *orc_auxr1d = NULL;   /* auxr: aux of the cell to the LEFT is orc_auxr1d(:, i-1); NULL = same array        */
 int orc_maux1d = 0;
+/* for transverse solvers with cell-wise coefficients: aux of the neighbouring slices (aux1 / aux3 of step2.f:97-101) */
+const double *orc_auxb1d = NULL, *orc_auxa1d = NULL;
 
 /* 2-D acoustics with cell-wise impedance and sound speed, restated (third-party rpn2_vc_acoustics.f; same
  * formulas as rpn3_vc_acoustics below); q = (p, u, v); aux(1) = Z, aux(2) = c */
@@ -445,6 +447,32 @@ static void rpn2_vc_acoustics(int ixy, int meqn, int mwaves, int mbc, int mx, co
         }
 #undef AX
 #undef AXR
+}
+
+/* transverse solver of the variable-coefficient acoustics equations, restated (third-party rpt2_vc_acoustics.f):
+ * the down-going part of asdq enters the slice below with ITS impedance and sound speed, the up-going part the
+ * slice above; i1 = i-2+imp is the cell asdq belongs to (left of the interface for amdq, right for apdq) */
+static void rpt2_vc_acoustics(int ixy, int imp, int meqn, int mbc, int mx, const double *asdq, double *bmasdq,
+                              double *bpasdq)
+{
+    const int maux = orc_maux1d;
+    const double *aux1 = orc_auxb1d, *aux2 = orc_aux1d, *aux3 = orc_auxa1d;
+#define AXN(arr, ma, i) arr[((ma)-1) + maux * IX(i)]
+    const int mu = ixy + 1, mv = (ixy == 1) ? 3 : 2;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const int i1 = i - 2 + imp;
+        const double zm = AXN(aux1, 1, i1), zz = AXN(aux2, 1, i1), zp = AXN(aux3, 1, i1);
+        const double cm = AXN(aux1, 2, i1), cp = AXN(aux3, 2, i1);
+        const double a1 = (-A2(asdq, 1, i) + A2(asdq, mv, i) * zz) / (zm + zz);
+        const double a2 = (A2(asdq, 1, i) + A2(asdq, mv, i) * zz) / (zz + zp);
+        A2(bmasdq, 1, i) = cm * a1 * zm;
+        A2(bmasdq, mu, i) = 0.0;
+        A2(bmasdq, mv, i) = -cm * a1;
+        A2(bpasdq, 1, i) = cp * a2 * zp;
+        A2(bpasdq, mu, i) = 0.0;
+        A2(bpasdq, mv, i) = cp * a2;
+    }
+#undef AXN
 }
 
 /* 2-D acoustics normal solver, restated (third-party rpn2_acoustics.f) */
@@ -724,9 +752,13 @@ static int rpn2_dispatch(int rp, int ixy, int meqn, int mwaves, int mbc, int mx,
 
 static int rpt2_dispatch(int rp, int ixy, int meqn, int mbc, int mx, const double *q,
                          const double *asdq, double *bmasdq, double *bpasdq,
-                         const double *par)
+                         const double *par, int imp)
 {
     switch (rp) {
+    case RP_VC_ACOUSTICS_2D:
+        if (!orc_aux1d || !orc_auxb1d || !orc_auxa1d) return -1;
+        rpt2_vc_acoustics(ixy, imp, meqn, mbc, mx, asdq, bmasdq, bpasdq);
+        return 0;
     case RP_ADVECTION_2D:
         rpt2_advection(ixy, meqn, mbc, mx, asdq, bmasdq, bpasdq, par);
         return 0;
@@ -842,13 +874,13 @@ static int flux2(int rp, const double *par, int fwave, int ixy, int meqn, int mw
                 A2(apdq, m, i) = A2(apdq, m, i) - A2(cqxx, m, i);
             }
 
-    if (rpt2_dispatch(rp, ixy, meqn, mbc, mx, q1d, amdq, bmasdq, bpasdq, par)) return -1;
+    if (rpt2_dispatch(rp, ixy, meqn, mbc, mx, q1d, amdq, bmasdq, bpasdq, par, 1)) return -1;
     for (int i = 1; i <= mx + 1; i++)
         for (int m = 1; m <= meqn; m++) {
             GADD(m, 1, i - 1) = GADD(m, 1, i - 1) - 0.5 * DT(i - 1) * A2(bmasdq, m, i);
             GADD(m, 2, i - 1) = GADD(m, 2, i - 1) - 0.5 * DT(i - 1) * A2(bpasdq, m, i);
         }
-    if (rpt2_dispatch(rp, ixy, meqn, mbc, mx, q1d, apdq, bmasdq, bpasdq, par)) return -1;
+    if (rpt2_dispatch(rp, ixy, meqn, mbc, mx, q1d, apdq, bmasdq, bpasdq, par, 2)) return -1;
     for (int i = 1; i <= mx + 1; i++)
         for (int m = 1; m <= meqn; m++) {
             GADD(m, 1, i) = GADD(m, 1, i) - 0.5 * DT(i) * A2(bmasdq, m, i);
@@ -957,6 +989,9 @@ int orc_step2(int rp, const double *par, int fwave, int maxm, int meqn, int mwav
     double cfl = 0.0, cfl1d;
     double dtdx = dt / dx, dtdy = dt / dy;
     int rc = 0;
+    const size_t nal = (size_t)(maxm + 2 * mbc) * (maux > 0 ? maux : 1);
+    double *aux1d = calloc(nal, sizeof(double)), *auxb = calloc(nal, sizeof(double)), *auxa = calloc(nal, sizeof(double));
+    orc_aux1d = aux1d; orc_auxb1d = auxb; orc_auxa1d = auxa; orc_maux1d = maux;
 
     /* x sweeps */
     if (mcapa == 0)
@@ -966,6 +1001,12 @@ int orc_step2(int rp, const double *par, int fwave, int maxm, int meqn, int mwav
             for (int i = 1 - mbc; i <= mx + mbc; i++) A2(q1d, m, i) = Q3(qold, m, i, j);
         if (mcapa > 0)
             for (int i = 1 - mbc; i <= mx + mbc; i++) dtdx1d[IX(i)] = dtdx / AUX3(mcapa, i, j);
+        for (int i = 1 - mbc; i <= mx + mbc; i++)        /* step2.f:97-101: aux rows j-1, j, j+1 */
+            for (int ma = 1; ma <= maux; ma++) {
+                auxb[(ma - 1) + maux * IX(i)] = AUX3(ma, i, j - 1);
+                aux1d[(ma - 1) + maux * IX(i)] = AUX3(ma, i, j);
+                auxa[(ma - 1) + maux * IX(i)] = AUX3(ma, i, j + 1);
+            }
         rc |= flux2(rp, par, fwave, 1, meqn, mwaves, mbc, mx, method, mthlim, &w, &cfl1d);
         cfl = dmax(cfl, cfl1d);
         if (mcapa == 0) {
@@ -1000,6 +1041,12 @@ int orc_step2(int rp, const double *par, int fwave, int maxm, int meqn, int mwav
             for (int j = 1 - mbc; j <= my + mbc; j++) A2(q1d, m, j) = Q3(qold, m, i, j);
         if (mcapa > 0)
             for (int j = 1 - mbc; j <= my + mbc; j++) dtdx1d[IX(j)] = dtdy / AUX3(mcapa, i, j);
+        for (int j = 1 - mbc; j <= my + mbc; j++)        /* step2.f:177-181: aux columns i-1, i, i+1 */
+            for (int ma = 1; ma <= maux; ma++) {
+                auxb[(ma - 1) + maux * IX(j)] = AUX3(ma, i - 1, j);
+                aux1d[(ma - 1) + maux * IX(j)] = AUX3(ma, i, j);
+                auxa[(ma - 1) + maux * IX(j)] = AUX3(ma, i + 1, j);
+            }
         rc |= flux2(rp, par, fwave, 2, meqn, mwaves, mbc, my, method, mthlim, &w, &cfl1d);
         cfl = dmax(cfl, cfl1d);
         if (mcapa == 0) {
@@ -1027,6 +1074,8 @@ int orc_step2(int rp, const double *par, int fwave, int maxm, int meqn, int mwav
         }
     }
     *cfl_out = cfl;
+    orc_aux1d = orc_auxb1d = orc_auxa1d = NULL;
+    free(aux1d); free(auxb); free(auxa);
     work_free(&w);
     return rc;
 }
@@ -1134,7 +1183,7 @@ int orc_rp1_ptr(int rp, const double *par, int meqn, int mwaves, int mbc, int mx
 int orc_rpt2(int rp, const double *par, int ixy, int meqn, int mbc, int mx,
              const double *q1d, const double *asdq, double *bmasdq, double *bpasdq)
 {
-    return rpt2_dispatch(rp, ixy, meqn, mbc, mx, q1d, asdq, bmasdq, bpasdq, par);
+    return rpt2_dispatch(rp, ixy, meqn, mbc, mx, q1d, asdq, bmasdq, bpasdq, par, 1);
 }
 
 void orc_limiter(int meqn, int mwaves, int mbc, int mx, double *wave, const double *s,

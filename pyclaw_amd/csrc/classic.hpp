@@ -94,7 +94,8 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                                           bool cfl_ok, const SweepArgs &a,
                                           double (&qn)[RP::MEQN], double &cflmax,
                                           double *df = nullptr, double *g1 = nullptr, double *g2 = nullptr,
-                                          const double *auxv = nullptr) {
+                                          const double *auxv = nullptr, const double *auxb = nullptr,
+                                          const double *auxa = nullptr) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     using Cell = typename RP::Cell;
 
@@ -239,15 +240,24 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                 for (int m = 0; m < MEQN; m++) { amdq[m] = amdq[m] + cq[m]; apdq[m] = apdq[m] - cq[m]; }
             }
             double bm[MEQN], bp[MEQN];
+            // solvers with cell-wise coefficients: aux of the cells below / above in the neighbouring slices --
+            // of this lane's cell for A^+ dq, of the left neighbour's (shifted) for A^- dq
+            double auxbl[RP::NAUX > 0 ? RP::NAUX : 1], auxal[RP::NAUX > 0 ? RP::NAUX : 1];
+            if constexpr (RP::NAUX > 0) {
+#pragma unroll
+                for (int k = 0; k < RP::NAUX; k++) { auxbl[k] = from_left(auxb[k]); auxal[k] = from_left(auxa[k]); }
+            }
             // B^-/B^+ A^- dq of interface l modify the cell to its LEFT (flux2.f:167-176)
-            RP::template transverse<IXY>(cL, cR, a.par, amdq, bm, bp);
+            if constexpr (RP::NAUX > 0) RP::template transverse_vc<IXY>(cL, auxbl, auxal, amdq, bm, bp);
+            else RP::template transverse<IXY>(cL, cR, a.par, amdq, bm, bp);
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
                 g1[m] = -(0.5 * dtdx_c * from_right(bm[m]));
                 g2[m] = -(0.5 * dtdx_c * from_right(bp[m]));
             }
             // B^-/B^+ A^+ dq of interface l modify this cell (flux2.f:180-189)
-            RP::template transverse<IXY>(cL, cR, a.par, apdq, bm, bp);
+            if constexpr (RP::NAUX > 0) RP::template transverse_vc<IXY>(cR, auxb, auxa, apdq, bm, bp);
+            else RP::template transverse<IXY>(cL, cR, a.par, apdq, bm, bp);
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
                 g1[m] = g1[m] - 0.5 * dtdx_c * bm[m];
@@ -621,7 +631,19 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, i
     for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + g];
     double cflmax = 0.0;
     const bool cfl_ok = slice_ok && (ca >= a.mbc) && (ca <= a.mbc + a.mx) && lane >= 1;
-    lane_core<RP, 1, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2);
+    // solver aux of this row and of the rows below / above it (step2.f:97-101: aux1, aux2, aux3)
+    constexpr int NAUX = RP::NAUX;
+    double auxv[NAUX > 0 ? NAUX : 1], auxb[NAUX > 0 ? NAUX : 1], auxa[NAUX > 0 ? NAUX : 1];
+    if constexpr (NAUX > 0) {
+        const int rb = rc > 0 ? rc - 1 : 0, ra = rc + 1 < a.J ? rc + 1 : a.J - 1;
+#pragma unroll
+        for (int m = 0; m < NAUX; m++) {
+            auxv[m] = a.aux[m * a.plane + g];
+            auxb[m] = a.aux[m * a.plane + (long)rb * a.pitch + cc];
+            auxa[m] = a.aux[m * a.plane + (long)ra * a.pitch + cc];
+        }
+    }
+    lane_core<RP, 1, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa);
 #pragma unroll
     for (int m = 0; m < MEQN; m++) {
         gm[w][m][lane] = a.dtd_t * g1[m];
@@ -674,7 +696,21 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
     for (int m = 0; m < MEQN; m++) q[m] = tile[m][lane][w];
     double cflmax = 0.0;
     const bool cfl_ok = slice_ok && (cj >= a.mbc) && (cj <= a.mbc + a.my) && lane >= 1;
-    lane_core<RP, 2, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2);
+    // solver aux of this column and of the columns to its left / right (step2.f:177-181)
+    constexpr int NAUX = RP::NAUX;
+    double auxv[NAUX > 0 ? NAUX : 1], auxb[NAUX > 0 ? NAUX : 1], auxa[NAUX > 0 ? NAUX : 1];
+    if constexpr (NAUX > 0) {
+        const int gj = cj < a.J ? cj : a.J - 1;
+        const int c0 = col < a.I ? col : a.I - 1;
+        const int cb = c0 > 0 ? c0 - 1 : 0, cn = c0 + 1 < a.I ? c0 + 1 : a.I - 1;
+#pragma unroll
+        for (int m = 0; m < NAUX; m++) {
+            auxv[m] = a.aux[m * a.plane + (long)gj * a.pitch + c0];
+            auxb[m] = a.aux[m * a.plane + (long)gj * a.pitch + cb];
+            auxa[m] = a.aux[m * a.plane + (long)gj * a.pitch + cn];
+        }
+    }
+    lane_core<RP, 2, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa);
 #pragma unroll
     for (int m = 0; m < MEQN; m++) {
         gm[w][m][lane] = a.dtd_t * g1[m];

@@ -172,6 +172,7 @@ int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
     if (l.rp == PCL_RP_ACOUSTICS_2D) return launch_unsplit_t<Acoustics2D>(l, qx, err);
     if (l.rp == PCL_RP_ADVECTION_2D) return launch_unsplit_t<Advection2D>(l, qx, err);
     if (l.rp == PCL_RP_SHALLOW_2D) return launch_unsplit_t<Shallow2D>(l, qx, err);
+    if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch_unsplit_t<VcAcoustics2D>(l, qx, err);
     if (l.rp == PCL_RP_EULER5_2D) return launch_unsplit_t<Euler5>(l, qx, err);
     err = "Riemann solver id is not a 2-D solver";
     return PCL_EINVAL;

@@ -437,8 +437,8 @@ struct Acoustics2D {
 };
 
 // ---- 2-D acoustics with cell-wise impedance and sound speed (third-party rpn2_vc_acoustics.f, restated: the
-// formulas of VcAcoustics3D below); q = (p, u, v); aux(1) = Z, aux(2) = c.  No transverse solver here:
-// rpt2_vc_acoustics needs the aux values of the neighbouring rows -- dimension-split and SharpClaw only.
+// formulas of VcAcoustics3D below); q = (p, u, v); aux(1) = Z, aux(2) = c.  The transverse solver
+// (rpt2_vc_acoustics.f, restated) needs the aux values of the two neighbouring slices: transverse_vc.
 struct VcAcoustics2D {
     static constexpr int MEQN = 3, MWAVES = 2, NAUX = 2;
     struct Cell { double q[3]; double z, c; };
@@ -473,6 +473,19 @@ struct VcAcoustics2D {
     template <int IXY>
     __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &, double (&s)[2]) {
         s[0] = -L.c; s[1] = R.c;
+    }
+    // c1 = the cell asdq belongs to (left of the interface for amdq, right for apdq); auxb / auxa = aux of the
+    // cells below / above it in the transverse direction.  The down-going part enters the slice below with that
+    // slice's impedance and sound speed, the up-going part the slice above.
+    template <int IXY>
+    __device__ static __forceinline__ void transverse_vc(const Cell &c1, const double *auxb, const double *auxa,
+                                                         const double (&asdq)[3], double (&bm)[3], double (&bp)[3]) {
+        constexpr int mu = IXY, mv = (IXY == 1) ? 2 : 1;
+        const double zm = auxb[0], zz = c1.z, zp = auxa[0], cm = auxb[1], cp = auxa[1];
+        const double a1 = fdiv_ieee(-asdq[0] + asdq[mv] * zz, zm + zz);
+        const double a2 = fdiv_ieee(asdq[0] + asdq[mv] * zz, zz + zp);
+        bm[0] = cm * a1 * zm; bm[mu] = 0.0; bm[mv] = -cm * a1;
+        bp[0] = cp * a2 * zp; bp[mu] = 0.0; bp[mv] = cp * a2;
     }
 };
 

@@ -39,7 +39,7 @@ rp_euler_1d = RiemannSolver("euler_1d", 4, 1, 3, 3, ["gamma", "gamma1"])        
 rp_shallow_1d = RiemannSolver("shallow_1d", 5, 1, 2, 2, ["g"])                       # rp1_shallow_roe_with_efix
 rp_advection_2d = RiemannSolver("advection_2d", 12, 2, 1, 1, ["u", "v"], True)
 rp_shallow_2d = RiemannSolver("shallow_2d", 13, 2, 3, 3, ["g"], True)             # rpn2/rpt2_shallow_roe_with_efix
-rp_vc_acoustics_2d = RiemannSolver("vc_acoustics_2d", 14, 2, 3, 2, [])           # aux(1)=Z, aux(2)=c; dim-split / SharpClaw
+rp_vc_acoustics_2d = RiemannSolver("vc_acoustics_2d", 14, 2, 3, 2, [], True)     # aux(1)=Z, aux(2)=c
 rp_acoustics_2d = RiemannSolver("acoustics_2d", 10, 2, 3, 2, ["rho", "bulk", "cc", "zz"], True)
 rp_euler_5wave_2d = RiemannSolver("euler_5wave_2d", 11, 2, 5, 5, ["gamma", "gamma1"], True)
 
