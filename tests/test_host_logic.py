@@ -130,3 +130,43 @@ def test_neighbors():
             for dd in range(8):
                 if na[dd] >= 0:
                     assert decs[na[dd]].neighbors(per)[opp[dd]] == a.rank
+
+
+def test_riemann_registry_and_limiter_ids():
+    import pyclaw_amd as pyclaw
+    from pyclaw_amd import riemann
+    ids = [r.id for r in riemann._ALL]
+    assert len(ids) == len(set(ids)) == 12
+    assert riemann.get('rp_euler_5wave_2d') is riemann.rp_euler_5wave_2d and riemann.get('burgers_1d').meqn == 1
+    assert riemann.rp_vc_acoustics_2d.has_transverse and riemann.rp_shallow_2d.cparam == ('g',)
+    with pytest.raises(Exception):
+        riemann.get('no_such_solver')
+    with pytest.raises(Exception):                       # cparam keys must be in aux_global (state.py:156-160)
+        riemann.rp_euler_1d.params({'gamma': 1.4})
+    t = pyclaw.limiters.tvd
+    assert (t.minmod, t.superbee, t.vanleer, t.MC) == (1, 2, 3, 4)
+
+
+def test_3d_decomposition_cuts_y_and_z_only():
+    from pyclaw_amd import parallel
+    for rank in range(8):
+        d = parallel.Decomposition([64, 48, 40], 8, rank)
+        assert d.axes == [1, 2] and d.ranges[0] == (0, 64)
+        assert d.dims[0] * d.dims[1] == 8
+    cover = np.zeros((48, 40), dtype=int)
+    for rank in range(8):
+        d = parallel.Decomposition([64, 48, 40], 8, rank)
+        cover[d.ranges[1][0]:d.ranges[1][1], d.ranges[2][0]:d.ranges[2][1]] += 1
+    assert (cover == 1).all()
+    d = parallel.Decomposition([64, 48, 40], 8, 0)
+    nb = d.neighbors([True, True, False])               # periodic in x (not cut) and y, not in z
+    assert nb[parallel.W] >= 0 or d.dims[0] == 1
+    assert nb[parallel.S] == -1                           # rank 0 sits at the lower z edge, z is not periodic
+
+
+def test_clawsolver3d_surface():
+    import pyclaw_amd as pyclaw
+    s = pyclaw.ClawSolver3D()
+    assert s.ndim == 3 and s.dim_split is True and s.order_trans == 22
+    assert (s.no_trans, s.trans_inc, s.trans_cor) == (0, 11, 22)
+    assert len(s.bc_lower) == 3
