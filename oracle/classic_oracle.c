@@ -54,6 +54,7 @@
 #define RP_ADVECTION_2D 12
 #define RP_SHALLOW_2D 13
 #define RP_VC_ACOUSTICS_2D 14
+#define RP_VC_ADVECTION_2D 15
 #define RP_VC_ACOUSTICS_3D 20
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
@@ -449,6 +450,32 @@ static void rpn2_vc_acoustics(int ixy, int meqn, int mwaves, int mbc, int mx, co
 #undef AXR
 }
 
+/* 2-D colour equation q_t + u(x,y) q_x + v(x,y) q_y = 0 with edge velocities, restated (third-party
+ * rpn2_vc_advection.f / rpt2_vc_advection.f, apps/advection/2d/annulus): aux(1) = u at the cell's left edge,
+ * aux(2) = v at its bottom edge */
+static void rpn2_vc_advection(int ixy, int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                              double *wave, double *s, double *amdq, double *apdq)
+{
+    const int maux = orc_maux1d;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const double vel = orc_aux1d[(ixy - 1) + maux * IX(i)];
+        W(1, 1, i) = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        S(1, i) = vel;
+        A2(amdq, 1, i) = dmin(vel, 0.0) * W(1, 1, i);
+        A2(apdq, 1, i) = dmax(vel, 0.0) * W(1, 1, i);
+    }
+}
+static void rpt2_vc_advection(int ixy, int imp, int meqn, int mbc, int mx, const double *asdq, double *bmasdq,
+                              double *bpasdq)
+{
+    const int maux = orc_maux1d, kv = 3 - ixy;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const int i1 = i - 2 + imp;
+        A2(bmasdq, 1, i) = dmin(orc_aux1d[(kv - 1) + maux * IX(i1)], 0.0) * A2(asdq, 1, i);
+        A2(bpasdq, 1, i) = dmax(orc_auxa1d[(kv - 1) + maux * IX(i1)], 0.0) * A2(asdq, 1, i);
+    }
+}
+
 /* transverse solver of the variable-coefficient acoustics equations, restated (third-party rpt2_vc_acoustics.f):
  * the down-going part of asdq enters the slice below with ITS impedance and sound speed, the up-going part the
  * slice above; i1 = i-2+imp is the cell asdq belongs to (left of the interface for amdq, right for apdq) */
@@ -740,6 +767,10 @@ static int rpn2_dispatch(int rp, int ixy, int meqn, int mwaves, int mbc, int mx,
         if (!orc_aux1d || orc_maux1d < 2) return -1;
         rpn2_vc_acoustics(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
         return 0;
+    case RP_VC_ADVECTION_2D:
+        if (!orc_aux1d || orc_maux1d < 2) return -1;
+        rpn2_vc_advection(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
+        return 0;
     case RP_ACOUSTICS_2D:
         rpn2_acoustics(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
@@ -758,6 +789,10 @@ static int rpt2_dispatch(int rp, int ixy, int meqn, int mbc, int mx, const doubl
     case RP_VC_ACOUSTICS_2D:
         if (!orc_aux1d || !orc_auxb1d || !orc_auxa1d) return -1;
         rpt2_vc_acoustics(ixy, imp, meqn, mbc, mx, asdq, bmasdq, bpasdq);
+        return 0;
+    case RP_VC_ADVECTION_2D:
+        if (!orc_aux1d || !orc_auxa1d) return -1;
+        rpt2_vc_advection(ixy, imp, meqn, mbc, mx, asdq, bmasdq, bpasdq);
         return 0;
     case RP_ADVECTION_2D:
         rpt2_advection(ixy, meqn, mbc, mx, asdq, bmasdq, bpasdq, par);

@@ -31,6 +31,7 @@ RP_ACOUSTICS_2D = 10
 RP_ADVECTION_2D = 12
 RP_SHALLOW_2D = 13
 RP_VC_ACOUSTICS_2D = 14
+RP_VC_ADVECTION_2D = 15
 RP_EULER5_2D = 11
 RP_VC_ACOUSTICS_3D = 20
 

@@ -73,12 +73,14 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 1, false>(l, err);
         if (rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 1, false>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 1, false>(l, err);
+        if (rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 1, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false>(l, err);
         if (rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 2, false>(l, err);
         if (rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 2, false>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 2, false>(l, err);
+        if (rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 2, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -173,6 +175,7 @@ int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
     if (l.rp == PCL_RP_ADVECTION_2D) return launch_unsplit_t<Advection2D>(l, qx, err);
     if (l.rp == PCL_RP_SHALLOW_2D) return launch_unsplit_t<Shallow2D>(l, qx, err);
     if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch_unsplit_t<VcAcoustics2D>(l, qx, err);
+    if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch_unsplit_t<VcAdvection2D>(l, qx, err);
     if (l.rp == PCL_RP_EULER5_2D) return launch_unsplit_t<Euler5>(l, qx, err);
     err = "Riemann solver id is not a 2-D solver";
     return PCL_EINVAL;
@@ -224,12 +227,14 @@ int launch_sharp(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 1>(l, err);
         if (rp == PCL_RP_SHALLOW_2D) return launch_sharp_t<Shallow2D, 1>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch_sharp_t<VcAcoustics2D, 1>(l, err);
+        if (rp == PCL_RP_VC_ADVECTION_2D) return launch_sharp_t<VcAdvection2D, 1>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 1>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 2>(l, err);
         if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 2>(l, err);
         if (rp == PCL_RP_SHALLOW_2D) return launch_sharp_t<Shallow2D, 2>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch_sharp_t<VcAcoustics2D, 2>(l, err);
+        if (rp == PCL_RP_VC_ADVECTION_2D) return launch_sharp_t<VcAdvection2D, 2>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 2>(l, err);
     }
     err = "Riemann solver id does not match the grid dimension";

@@ -517,6 +517,7 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     case PCL_RP_ADVECTION_2D: want_meqn = 1; want_mwaves = 1; want_ndim = 2; break;
     case PCL_RP_SHALLOW_2D: want_meqn = 3; want_mwaves = 3; want_ndim = 2; break;
     case PCL_RP_VC_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
+    case PCL_RP_VC_ADVECTION_2D: want_meqn = 1; want_mwaves = 1; want_ndim = 2; break;
     case PCL_RP_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
     case PCL_RP_EULER5_2D: want_meqn = 5; want_mwaves = 5; want_ndim = 2; break;
     case PCL_RP_VC_ACOUSTICS_3D: want_meqn = 4; want_mwaves = 2; want_ndim = 3; break;
@@ -529,8 +530,8 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (cfg->method[5] < 0 || cfg->method[5] > cfg->maux) return fail(PCL_EINVAL, "mcapa out of range");
     if (cfg->rp == PCL_RP_ADVECTION_COLOR_1D && cfg->maux < 1)
         return fail(PCL_EINVAL, "rp1_advection_color needs aux(1) = edge velocity");
-    if (cfg->rp == PCL_RP_VC_ACOUSTICS_2D) {
-        if (cfg->maux < 2) return fail(PCL_EINVAL, "rpn2_vc_acoustics needs aux(1)=impedance, aux(2)=sound speed");
+    if (cfg->rp == PCL_RP_VC_ACOUSTICS_2D || cfg->rp == PCL_RP_VC_ADVECTION_2D) {
+        if (cfg->maux < 2) return fail(PCL_EINVAL, "this Riemann solver needs two aux components (impedance/sound speed or the edge velocities)");
         if (cfg->kind == PCL_KIND_CLASSIC && cfg->method[2] >= 0 && cfg->method[5] > 0)
             return fail(PCL_EINVAL, "rpn2/rpt2_vc_acoustics: the unsplit step with a capacity function is not built");
     }

@@ -436,6 +436,41 @@ struct Acoustics2D {
     }
 };
 
+// ---- 2-D colour equation with edge velocities (third-party rpn2_vc_advection.f / rpt2_vc_advection.f, restated):
+// aux(1) = u at the cell's left edge, aux(2) = v at its bottom edge
+struct VcAdvection2D {
+    static constexpr int MEQN = 1, MWAVES = 1, NAUX = 2;
+    struct Cell { double q[1]; double u, v; };
+    template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &, const double *auxv) {
+        Cell c; c.q[0] = q[0]; c.u = auxv[0]; c.v = auxv[1]; return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &,
+                                                 double (&wave)[1][1], double (&s)[1], double (&amdq)[1],
+                                                 double (&apdq)[1]) {
+        const double vel = IXY == 1 ? R.u : R.v;
+        wave[0][0] = R.q[0] - L.q[0];
+        s[0] = vel;
+        amdq[0] = dmin(vel, 0.0) * wave[0][0];
+        apdq[0] = dmax(vel, 0.0) * wave[0][0];
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &, const Cell &R, const RpParams &, double (&s)[1]) {
+        s[0] = IXY == 1 ? R.u : R.v;
+    }
+    // down-going part: the transverse velocity at this cell's own lower edge; up-going: at the lower edge of the
+    // cell above (auxa)
+    template <int IXY>
+    __device__ static __forceinline__ void transverse_vc(const Cell &c1, const double * /*auxb*/, const double *auxa,
+                                                         const double (&asdq)[1], double (&bm)[1], double (&bp)[1]) {
+        const double own = IXY == 1 ? c1.v : c1.u, above = IXY == 1 ? auxa[1] : auxa[0];
+        bm[0] = dmin(own, 0.0) * asdq[0];
+        bp[0] = dmax(above, 0.0) * asdq[0];
+    }
+};
+
 // ---- 2-D acoustics with cell-wise impedance and sound speed (third-party rpn2_vc_acoustics.f, restated: the
 // formulas of VcAcoustics3D below); q = (p, u, v); aux(1) = Z, aux(2) = c.  The transverse solver
 // (rpt2_vc_acoustics.f, restated) needs the aux values of the two neighbouring slices: transverse_vc.

@@ -40,6 +40,7 @@ rp_shallow_1d = RiemannSolver("shallow_1d", 5, 1, 2, 2, ["g"])                  
 rp_advection_2d = RiemannSolver("advection_2d", 12, 2, 1, 1, ["u", "v"], True)
 rp_shallow_2d = RiemannSolver("shallow_2d", 13, 2, 3, 3, ["g"], True)             # rpn2/rpt2_shallow_roe_with_efix
 rp_vc_acoustics_2d = RiemannSolver("vc_acoustics_2d", 14, 2, 3, 2, [], True)     # aux(1)=Z, aux(2)=c
+rp_vc_advection_2d = RiemannSolver("vc_advection_2d", 15, 2, 1, 1, [], True)     # aux(1)=u at left edge, aux(2)=v at bottom edge
 rp_acoustics_2d = RiemannSolver("acoustics_2d", 10, 2, 3, 2, ["rho", "bulk", "cc", "zz"], True)
 rp_euler_5wave_2d = RiemannSolver("euler_5wave_2d", 11, 2, 5, 5, ["gamma", "gamma1"], True)
 
@@ -47,7 +48,7 @@ rp_euler_5wave_2d = RiemannSolver("euler_5wave_2d", 11, 2, 5, 5, ["gamma", "gamm
 # rpn3_vc_acoustics.f; the transverse rpt3/rptt3 of the unsplit algorithm are not built: dim_split only)
 rp_vc_acoustics_3d = RiemannSolver("vc_acoustics_3d", 20, 3, 4, 2, [])
 
-_ALL = [rp_advection_1d, rp_acoustics_1d, rp_advection_color_1d, rp_burgers_1d, rp_euler_1d, rp_shallow_1d, rp_advection_2d, rp_shallow_2d, rp_vc_acoustics_2d, rp_acoustics_2d, rp_euler_5wave_2d, rp_vc_acoustics_3d]
+_ALL = [rp_advection_1d, rp_acoustics_1d, rp_advection_color_1d, rp_burgers_1d, rp_euler_1d, rp_shallow_1d, rp_advection_2d, rp_shallow_2d, rp_vc_acoustics_2d, rp_vc_advection_2d, rp_acoustics_2d, rp_euler_5wave_2d, rp_vc_acoustics_3d]
 BY_NAME = dict((r.name, r) for r in _ALL)
 
 

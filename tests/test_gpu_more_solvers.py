@@ -437,3 +437,57 @@ def test_vc_acoustics2d_unsplit_uniform_medium_equals_constant_coefficient():
     claw.run()
     assert claw.solver.status['numsteps'] == const.solver.status['numsteps']
     assert np.array_equal(claw.frames[-1].state.q, const.frames[-1].state.q)
+
+
+@pytest.mark.parametrize("shape", [(14, 10), (80, 125)])
+def test_vc_advection2d_all_kernel_families(coracle, shape):
+    """rpn2/rpt2_vc_advection (edge velocities in aux): dim-split with a capacity function in a third aux field
+    (the annulus app's set-up), unsplit with transverse terms, SharpClaw -- device == C restatement; and with
+    uniform velocities it equals the constant-coefficient solver rpn2/rpt2_advection bit for bit."""
+    from pyclaw_amd import _lib as L
+    mx, my = shape
+    rng = np.random.default_rng(mx)
+    cfl = C.c_double()
+    mth = np.array([4], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.2 / max(mx, my)
+    q0 = np.asfortranarray(rng.random((1, mx + 4, my + 4)))
+    aux = np.asfortranarray(np.concatenate([1.5 * (rng.random((2, mx + 4, my + 4)) - 0.4),
+                                            0.5 + rng.random((1, mx + 4, my + 4))]))
+    method = np.array([1, 2, -1, 0, 0, 3, 3], dtype=np.int32)        # mcapa = 3
+    for ids in (1, 2):
+        ref = q0.copy("F")
+        _, cfl_ref = coracle.step2ds(O.RP_VC_ADVECTION_2D, [0.0], max(mx, my), 2, mx, my, q0.copy("F"), ref, aux, dx, dy,
+                                     dt, method, mth, ids)
+        out = q0.copy("F")
+        L.check(L.lib().pcl_step2ds(O.RP_VC_ADVECTION_2D, None, 0, 1, 1, 3, 2, mx, my, L.d(q0), L.d(out), L.d(aux), dx,
+                                    dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp), ids))
+        assert np.array_equal(out, ref) and cfl.value == cfl_ref and cfl.value > 0
+    aux2 = np.asfortranarray(aux[:2])
+    inner = (slice(None), slice(2, -2), slice(2, -2))
+    for trans in (0, 1, 2):
+        method = np.array([1, 2, trans, 0, 0, 0, 2], dtype=np.int32)
+        ref = q0.copy("F")
+        _, cfl_ref = coracle.step2(O.RP_VC_ADVECTION_2D, [0.0], max(mx, my), 2, mx, my, q0.copy("F"), ref, aux2, dx, dy, dt,
+                                   method, mth)
+        out = q0.copy("F")
+        L.check(L.lib().pcl_step2(O.RP_VC_ADVECTION_2D, None, 0, 1, 1, 2, 2, mx, my, L.d(q0), L.d(out), L.d(aux2), dx, dy,
+                                  dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+        assert np.array_equal(out[inner], ref[inner]) and cfl.value == cfl_ref
+        # uniform velocity field == constant-coefficient advection
+        uni = np.empty_like(aux2)
+        uni[0], uni[1] = 0.7, -0.4
+        a = q0.copy("F")
+        L.check(L.lib().pcl_step2(O.RP_VC_ADVECTION_2D, None, 0, 1, 1, 2, 2, mx, my, L.d(q0), L.d(a), L.d(uni), dx, dy,
+                                  dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+        b = q0.copy("F")
+        m0 = method.copy(); m0[6] = 0
+        L.check(L.lib().pcl_step2(O.RP_ADVECTION_2D, L.d(np.array([0.7, -0.4] + [0.0] * 6)), 0, 1, 1, 0, 2, mx, my,
+                                  L.d(q0), L.d(b), None, dx, dy, dt, L.i(m0), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+        assert np.array_equal(a[inner], b[inner])
+    q3 = np.asfortranarray(rng.random((1, mx + 6, my + 6)))
+    a3 = np.asfortranarray(1.5 * (rng.random((2, mx + 6, my + 6)) - 0.4))
+    ref, cfl_ref = coracle.sharp_flux2(O.RP_VC_ADVECTION_2D, [0.0], 2, 1, 0, 3, mx, my, q3, a3, dx, dy, dt)
+    dq = np.zeros_like(q3)
+    L.check(L.lib().pcl_sharp_flux2(O.RP_VC_ADVECTION_2D, None, 2, 1, 1, 2, 0, 3, mx, my, L.d(q3), L.d(dq), L.d(a3), dx,
+                                    dy, dt, C.cast(C.byref(cfl), L.dp)))
+    assert np.array_equal(dq[:, 3:-3, 3:-3], ref[:, 3:-3, 3:-3]) and cfl.value == cfl_ref

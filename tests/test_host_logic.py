@@ -136,7 +136,7 @@ def test_riemann_registry_and_limiter_ids():
     import pyclaw_amd as pyclaw
     from pyclaw_amd import riemann
     ids = [r.id for r in riemann._ALL]
-    assert len(ids) == len(set(ids)) == 12
+    assert len(ids) == len(set(ids)) == 13
     assert riemann.get('rp_euler_5wave_2d') is riemann.rp_euler_5wave_2d and riemann.get('burgers_1d').meqn == 1
     assert riemann.rp_vc_acoustics_2d.has_transverse and riemann.rp_shallow_2d.cparam == ('g',)
     with pytest.raises(Exception):
