@@ -57,7 +57,7 @@ extern "C" {
 #define PCL_RP_EULER5_2D 11    /* rpn2/rpt2_euler_5wave.f   cparam: gamma,gamma1        */
 #define PCL_RP_ADVECTION_2D 12  /* rpn2/rpt2_advection.f      cparam: u,v                  */
 #define PCL_RP_SHALLOW_2D 13    /* rpn2/rpt2_shallow_roe_with_efix.f  cparam: g            */
-#define PCL_RP_VC_ACOUSTICS_2D 14 /* rpn2/rpt2_vc_acoustics.f; aux(1)=Z, aux(2)=c (unsplit: without a capacity function) */
+#define PCL_RP_VC_ACOUSTICS_2D 14 /* rpn2/rpt2_vc_acoustics.f; aux(1)=Z, aux(2)=c */
 #define PCL_RP_VC_ADVECTION_2D 15 /* rpn2/rpt2_vc_advection.f; aux(1)=u at the left edge, aux(2)=v at the bottom edge */
 #define PCL_RP_VC_ACOUSTICS_3D 20 /* rpn3_vc_acoustics.f (test/acoustics/3d/Makefile); aux(1)=Z, aux(2)=c; dim-split only */
 

@@ -527,7 +527,20 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             // unsplit algorithm: this slice's pieces for the cell go to scratch planes; they are
             // summed into qnew in the reference's order by combine_kernel (step2.f:130-137,214-218)
             double df[MEQN], g1[MEQN], g2[MEQN];
-            lane_core<RP, IXY, CAPA, FWAVE, DIM1, true>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, df, g1, g2, auxv);
+            // transverse solvers with cell-wise coefficients: aux of the cells in the slices below / above
+            double auxb[NAUX > 0 ? NAUX : 1], auxa[NAUX > 0 ? NAUX : 1];
+            if constexpr (NAUX > 0) {
+                const int gbc = b0 + ac < n_across ? b0 + ac : n_across - 1;
+                const int gbb = gbc > 0 ? gbc - 1 : 0, gba = gbc + 1 < n_across ? gbc + 1 : n_across - 1;
+                const int cac = ca < n_along ? ca : n_along - 1;
+#pragma unroll
+                for (int m = 0; m < NAUX; m++) {
+                    auxb[m] = a.aux[m * a.plane + (IXY == 1 ? (long)gbb * a.pitch + cac : (long)cac * a.pitch + gbb)];
+                    auxa[m] = a.aux[m * a.plane + (IXY == 1 ? (long)gba * a.pitch + cac : (long)cac * a.pitch + gba)];
+                }
+            }
+            lane_core<RP, IXY, CAPA, FWAVE, DIM1, true>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, df, g1, g2, auxv, auxb,
+                                                        auxa);
             if (owned) {
                 const int gb = b0 + ac;
                 const long g = IXY == 1 ? (long)gb * a.pitch + ca : (long)ca * a.pitch + gb;

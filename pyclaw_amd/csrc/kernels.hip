@@ -129,11 +129,15 @@ int launch_slices(const SweepLaunch &l, std::string &err) {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 1, false, true>(l, err);
+        if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 1, false, true>(l, err);
+        if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false, true>(l, err);
     } else {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 2, false, true>(l, err);
+        if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 2, false, true>(l, err);
+        if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false, true>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";

@@ -532,8 +532,6 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
         return fail(PCL_EINVAL, "rp1_advection_color needs aux(1) = edge velocity");
     if (cfg->rp == PCL_RP_VC_ACOUSTICS_2D || cfg->rp == PCL_RP_VC_ADVECTION_2D) {
         if (cfg->maux < 2) return fail(PCL_EINVAL, "this Riemann solver needs two aux components (impedance/sound speed or the edge velocities)");
-        if (cfg->kind == PCL_KIND_CLASSIC && cfg->method[2] >= 0 && cfg->method[5] > 0)
-            return fail(PCL_EINVAL, "rpn2/rpt2_vc_acoustics: the unsplit step with a capacity function is not built");
     }
     if (cfg->ndim == 3) {
         if (cfg->kind != PCL_KIND_CLASSIC) return fail(PCL_EINVAL, "3-D: classic solver only (the reference has no 3-D SharpClaw)");

@@ -491,3 +491,28 @@ def test_vc_advection2d_all_kernel_families(coracle, shape):
     L.check(L.lib().pcl_sharp_flux2(O.RP_VC_ADVECTION_2D, None, 2, 1, 1, 2, 0, 3, mx, my, L.d(q3), L.d(dq), L.d(a3), dx,
                                     dy, dt, C.cast(C.byref(cfl), L.dp)))
     assert np.array_equal(dq[:, 3:-3, 3:-3], ref[:, 3:-3, 3:-3]) and cfl.value == cfl_ref
+
+
+@pytest.mark.parametrize("rp_name", ["vc_advection", "vc_acoustics"])
+@pytest.mark.parametrize("trans", [0, 2])
+def test_vc_solvers_unsplit_with_capacity_function(coracle, rp_name, trans):
+    """the annulus app's configuration (apps/advection/2d/annulus: unsplit, order_trans=2, mcapa=2 -> third aux
+    component): per-slice pieces through the scratch planes, every increment divided by capa of its target cell"""
+    from pyclaw_amd import _lib as L
+    mx, my = 44, 57
+    rng = np.random.default_rng(trans)
+    meqn, mw, rp = (1, 1, O.RP_VC_ADVECTION_2D) if rp_name == "vc_advection" else (3, 2, O.RP_VC_ACOUSTICS_2D)
+    q0 = np.asfortranarray(rng.standard_normal((meqn, mx + 4, my + 4)))
+    first = 1.5 * (rng.random((2, mx + 4, my + 4)) - 0.4) if meqn == 1 else 0.5 + 2.0 * rng.random((2, mx + 4, my + 4))
+    aux = np.asfortranarray(np.concatenate([first, 0.5 + rng.random((1, mx + 4, my + 4))]))
+    method = np.array([1, 2, trans, 0, 0, 3, 3], dtype=np.int32)
+    mth = np.array([4] * mw, dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.002
+    ref = q0.copy("F")
+    _, cfl_ref = coracle.step2(rp, [0.0], max(mx, my), 2, mx, my, q0.copy("F"), ref, aux, dx, dy, dt, method, mth)
+    out = q0.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2(rp, None, 0, meqn, mw, 3, 2, mx, my, L.d(q0), L.d(out), L.d(aux), dx, dy, dt,
+                              L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None), slice(2, -2), slice(2, -2))
+    assert np.array_equal(out[inner], ref[inner]) and cfl.value == cfl_ref and cfl.value > 0
