@@ -12,7 +12,7 @@ unchanged; 'Python' (the reference's pure-numpy 1-D kernel) is not provided.
 import numpy as np
 
 from . import _lib, riemann
-from .solver import Solver, DeviceBC
+from .solver import Solver
 
 
 class DeviceSource(object):

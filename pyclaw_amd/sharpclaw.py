@@ -19,8 +19,7 @@ import ctypes
 import numpy as np
 
 from . import _lib, riemann
-from .solver import Solver, BC
-from .state import State
+from .solver import Solver
 
 Q, S1, S2, DQ, TMP = 0, 1, 2, 3, 4
 

@@ -4,14 +4,12 @@ CPU oracle on the same seeded inputs -- bit for bit (PCL_MATH_EXACT) -- and agai
 reference's own golden files.
 """
 import ctypes as C
-import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-from oracle import driver as D
 from oracle import oracle as O
 
 
