@@ -309,3 +309,78 @@ def acoustics3D(pyclaw, test='hom', mx=None, my=None, mz=None, run=True, math='e
         return claw
     claw.run()
     return claw
+
+
+# ---------------------------------------------------------------------------------------------------
+# Further set-ups in the style of the reference's apps/ directory (no golden in the reference: the GPU tests check
+# them against exact physics or the oracle driver, tests/test_gpu_more_solvers.py)
+# ---------------------------------------------------------------------------------------------------
+def sod_shock_tube(pyclaw, n=800, tfinal=0.2, solver_type='classic'):
+    """apps/euler/1d style: Sod's Riemann problem with rp_euler_1d (Roe + entropy fix)."""
+    solver = pyclaw.ClawSolver1D() if solver_type == 'classic' else pyclaw.SharpClawSolver1D()
+    solver.rp = pyclaw.riemann.rp_euler_1d
+    solver.mwaves = 3
+    solver.limiters = [4, 4, 4]
+    solver.bc_lower[0] = solver.bc_upper[0] = pyclaw.BC.outflow
+    state = pyclaw.State(pyclaw.Grid(pyclaw.Dimension('x', 0.0, 1.0, n)), 3)
+    state.aux_global['gamma'] = gamma
+    state.aux_global['gamma1'] = gamma1
+    xc = state.grid.x.center
+    state.q[0] = np.where(xc < 0.5, 1.0, 0.125)
+    state.q[1] = 0.0
+    state.q[2] = np.where(xc < 0.5, 1.0, 0.1) / gamma1
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.solution = pyclaw.Solution(state)
+    claw.solver = solver
+    claw.tfinal, claw.nout = tfinal, 1
+    solver.dt_initial = 1e-4
+    claw.run()
+    return claw
+
+
+def radial_dam_break(pyclaw, n=200, tfinal=1.0, dim_split=False, solver_type='classic'):
+    """apps/shallow/2d style: radial dam break with rp_shallow_2d (Roe + entropy fix, transverse solver)."""
+    solver = pyclaw.ClawSolver2D() if solver_type == 'classic' else pyclaw.SharpClawSolver2D()
+    solver.rp = pyclaw.riemann.rp_shallow_2d
+    solver.mwaves = 3
+    solver.limiters = [4, 4, 4]
+    if solver_type == 'classic':
+        solver.dim_split = dim_split
+        solver.order_trans = 2
+    for k in range(2):
+        solver.bc_lower[k] = solver.bc_upper[k] = pyclaw.BC.outflow
+    grid = pyclaw.Grid([pyclaw.Dimension('x', -2.5, 2.5, n), pyclaw.Dimension('y', -2.5, 2.5, n)])
+    state = pyclaw.State(grid, 3)
+    state.aux_global['g'] = 1.0
+    X, Y = grid.c_center
+    r = np.sqrt(X ** 2 + Y ** 2)
+    state.q[0] = 2.0 * (r <= 0.5) + 1.0 * (r > 0.5)
+    state.q[1:] = 0.0
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.solution = pyclaw.Solution(state)
+    claw.solver = solver
+    claw.tfinal, claw.nout = tfinal, 1
+    solver.dt_initial = 1e-3
+    claw.run()
+    return claw
+
+
+def burgers_1d(pyclaw, n=400, tfinal=0.5):
+    """apps/burgers/1d style: a step that steepens into a shock moving at the Rankine-Hugoniot speed 1/2."""
+    solver = pyclaw.ClawSolver1D()
+    solver.rp = pyclaw.riemann.rp_burgers_1d
+    solver.mwaves = 1
+    solver.limiters = pyclaw.limiters.tvd.vanleer
+    solver.bc_lower[0] = solver.bc_upper[0] = pyclaw.BC.outflow
+    state = pyclaw.State(pyclaw.Grid(pyclaw.Dimension('x', 0.0, 1.0, n)), 1)
+    state.q[0, :] = 1.0 * (state.grid.x.center < 0.25)
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.solution = pyclaw.Solution(state)
+    claw.solver = solver
+    claw.tfinal, claw.nout = tfinal, 1
+    solver.dt_initial = 0.001
+    claw.run()
+    return claw
