@@ -260,6 +260,10 @@ int pcl_kernel_timing_read(pcl_solver *s, double *ms_total, long *launches);
 int pcl_comm_unique_id(char uid[128]);
 int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128],
                   const int neighbors[8]);
+/* Host-only argument check of pcl_comm_init (no GPU, no RCCL): rank inside 0..nranks-1, every neighbour a
+ * rank of the communicator or -1, a self-neighbour only on both faces of a dimension.  pcl_comm_init runs it
+ * first, so misuse fails with a message instead of RCCL's "invalid usage". */
+int pcl_comm_check(int nranks, int rank, const int neighbors[8]);
 int pcl_halo_exchange(pcl_solver *s);          /* faces + corners, width mbc            */
 int pcl_halo_exchange_aux(pcl_solver *s);
 int pcl_allreduce_max(pcl_solver *s, double *value);

@@ -55,6 +55,7 @@
 #define RP_SHALLOW_2D 13
 #define RP_VC_ACOUSTICS_2D 14
 #define RP_VC_ADVECTION_2D 15
+#define RP_SHALLOW_SPHERE_2D 16
 #define RP_VC_ACOUSTICS_3D 20
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
@@ -502,6 +503,226 @@ static void rpt2_vc_acoustics(int ixy, int imp, int meqn, int mbc, int mx, const
 #undef AXN
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Shallow water on the sphere (Calhoun, Helzel & LeVeque, SIAM Review 50 (2008) 723-752), 3-D Cartesian momentum:
+ * q = (h, hu, hv, hw), 3 waves, 16 aux components laid out by the reference's setaux.f:10-25
+ * (test/shallow_sphere/setaux.f; 1 kappa, 2-4 / 5-7 normal and tangent of the LEFT edge, 8-10 / 11-13 of the
+ * BOTTOM edge, 14-16 radial unit vector at the cell centre).
+ *
+ * The Riemann solvers rpn2_shallow_sphere.f / rpt2_shallow_sphere.f are THIRD-PARTY (clawpack/riemann, named by
+ * test/shallow_sphere/Makefile:7 as $(RIEMANN)/src/..., no version pinned) and absent from the reference tree:
+ * restated here from the published algorithm -- Roe solver in the edge-normal / edge-tangent frame, waves rotated
+ * back to Cartesian momentum, Harten-Hyman entropy fix, fluctuations projected onto the tangent plane of the cell
+ * they enter; speeds scaled by (edge length / computational cell width).  PARITY of these two routines is pinned only
+ * through the reference's golden test/swsphere_height at its own gate (2-norm < 1e-4, test/test_examples.py:456-472).
+ * par = g (common /sw/), dxcom, dycom (common /comxyt/, set by the app: shallow_4_Rossby_Haurwitz_wave.py:449-451).
+ * ------------------------------------------------------------------------------------------------------------ */
+static void rpn2_sphere(int ixy, int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                        double *wave, double *s, double *amdq, double *apdq, const double *par)
+{
+    const double *auxl = orc_aux1d, *auxr = orc_auxr1d ? orc_auxr1d : orc_aux1d;
+    const int maux = orc_maux1d;
+    const double g = par[0];
+    const double dy = (ixy == 1) ? par[2] : par[1];
+    const int ioff = (ixy == 1) ? 1 : 7;
+#define AXL(ma, i) auxl[((ma)-1) + maux * IX(i)]
+#define AXR(ma, i) auxr[((ma)-1) + maux * IX(i)]
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        double enx = AXL(ioff + 1, i), eny = AXL(ioff + 2, i), enz = AXL(ioff + 3, i);
+        double etx = AXL(ioff + 4, i), ety = AXL(ioff + 5, i), etz = AXL(ioff + 6, i);
+        const double gamma = sqrt(etx * etx + ety * ety + etz * etz);
+        etx = etx / gamma; ety = ety / gamma; etz = etz / gamma;
+        /* normal and tangential momentum at the edge: "l" = ql(i) (right of the interface), "r" = qr(i-1) */
+        const double hunl = enx * A2(ql, 2, i) + eny * A2(ql, 3, i) + enz * A2(ql, 4, i);
+        const double hunr = enx * A2(qr, 2, i - 1) + eny * A2(qr, 3, i - 1) + enz * A2(qr, 4, i - 1);
+        const double hutl = etx * A2(ql, 2, i) + ety * A2(ql, 3, i) + etz * A2(ql, 4, i);
+        const double hutr = etx * A2(qr, 2, i - 1) + ety * A2(qr, 3, i - 1) + etz * A2(qr, 4, i - 1);
+        /* Roe averages */
+        const double h = (A2(qr, 1, i - 1) + A2(ql, 1, i)) * 0.50;
+        const double hsqr = sqrt(A2(qr, 1, i - 1)), hsql = sqrt(A2(ql, 1, i)), hsq = hsqr + hsql;
+        const double u = (hunr / hsqr + hunl / hsql) / hsq;
+        const double v = (hutr / hsqr + hutl / hsql) / hsq;
+        const double a = sqrt(g * h);
+        const double delta1 = A2(ql, 1, i) - A2(qr, 1, i - 1);
+        const double delta2 = hunl - hunr;
+        const double delta3 = hutl - hutr;
+        const double a1 = ((u + a) * delta1 - delta2) * (0.50 / a);
+        const double a2 = -v * delta1 + delta3;
+        const double a3 = (-(u - a) * delta1 + delta2) * (0.50 / a);
+        W(1, 1, i) = a1;
+        W(2, 1, i) = a1 * (u - a) * enx + a1 * v * etx;
+        W(3, 1, i) = a1 * (u - a) * eny + a1 * v * ety;
+        W(4, 1, i) = a1 * (u - a) * enz + a1 * v * etz;
+        S(1, i) = (u - a) * gamma / dy;
+        W(1, 2, i) = 0.0;
+        W(2, 2, i) = a2 * etx;
+        W(3, 2, i) = a2 * ety;
+        W(4, 2, i) = a2 * etz;
+        S(2, i) = u * gamma / dy;
+        W(1, 3, i) = a3;
+        W(2, 3, i) = a3 * (u + a) * enx + a3 * v * etx;
+        W(3, 3, i) = a3 * (u + a) * eny + a3 * v * ety;
+        W(4, 3, i) = a3 * (u + a) * enz + a3 * v * etz;
+        S(3, i) = (u + a) * gamma / dy;
+
+        /* Harten-Hyman entropy fix: amdq = sum of s*wave over the left-going parts */
+        for (int m = 1; m <= 4; m++) A2(amdq, m, i) = 0.0;
+        int done = 0;
+        const double him1 = A2(qr, 1, i - 1);
+        const double s0 = (hunr / him1 - sqrt(g * him1)) * gamma / dy;
+        if (s0 > 0.0 && S(1, i) > 0.0) done = 1;            /* fully supersonic to the right */
+        if (!done) {
+            const double h1 = A2(qr, 1, i - 1) + W(1, 1, i);
+            const double hu1 = hunr + enx * W(2, 1, i) + eny * W(3, 1, i) + enz * W(4, 1, i);
+            const double s1 = (hu1 / h1 - sqrt(g * h1)) * gamma / dy;
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0) sfract = s0 * ((s1 - S(1, i)) / (s1 - s0));
+            else if (S(1, i) < 0.0) sfract = S(1, i);
+            else sfract = 0.0;
+            for (int m = 1; m <= 4; m++) A2(amdq, m, i) = sfract * W(m, 1, i);
+            if (S(2, i) > 0.0) done = 1;                    /* 2- and 3-waves go right */
+        }
+        if (!done) {
+            for (int m = 1; m <= 4; m++) A2(amdq, m, i) = A2(amdq, m, i) + S(2, i) * W(m, 2, i);
+            const double hi = A2(ql, 1, i);
+            const double s03 = (hunl / hi + sqrt(g * hi)) * gamma / dy;
+            const double h3 = A2(ql, 1, i) - W(1, 3, i);
+            const double hu3 = hunl - (enx * W(2, 3, i) + eny * W(3, 3, i) + enz * W(4, 3, i));
+            const double s3 = (hu3 / h3 + sqrt(g * h3)) * gamma / dy;
+            double sfract = 0.0;
+            int add = 1;
+            if (s3 < 0.0 && s03 > 0.0) sfract = s3 * ((s03 - S(3, i)) / (s03 - s3));
+            else if (S(3, i) < 0.0) sfract = S(3, i);
+            else add = 0;
+            if (add) for (int m = 1; m <= 4; m++) A2(amdq, m, i) = A2(amdq, m, i) + sfract * W(m, 3, i);
+        }
+        for (int m = 1; m <= 4; m++) {
+            double df = 0.0;
+            for (int mw = 1; mw <= mwaves; mw++) df = df + S(mw, i) * W(m, mw, i);
+            A2(apdq, m, i) = df - A2(amdq, m, i);
+        }
+        /* project the momentum parts onto the tangent plane of the cell each fluctuation enters */
+        {
+            const double erx = AXR(14, i - 1), ery = AXR(15, i - 1), erz = AXR(16, i - 1);
+            const double amn = erx * A2(amdq, 2, i) + ery * A2(amdq, 3, i) + erz * A2(amdq, 4, i);
+            A2(amdq, 2, i) = A2(amdq, 2, i) - amn * erx;
+            A2(amdq, 3, i) = A2(amdq, 3, i) - amn * ery;
+            A2(amdq, 4, i) = A2(amdq, 4, i) - amn * erz;
+        }
+        {
+            const double erx = AXL(14, i), ery = AXL(15, i), erz = AXL(16, i);
+            const double apn = erx * A2(apdq, 2, i) + ery * A2(apdq, 3, i) + erz * A2(apdq, 4, i);
+            A2(apdq, 2, i) = A2(apdq, 2, i) - apn * erx;
+            A2(apdq, 3, i) = A2(apdq, 3, i) - apn * ery;
+            A2(apdq, 4, i) = A2(apdq, 4, i) - apn * erz;
+        }
+    }
+#undef AXL
+#undef AXR
+}
+
+/* Transverse solver, restated (third-party rpt2_shallow_sphere.f).  asdq sits in cell i1 = i-2+imp (left of the
+ * interface for A^-dq, right for A^+dq).  Up-going part: Roe-type split in the frame of the edge ABOVE that cell
+ * (= the bottom/left edge of the cell in the next slice, aux3) with the cell's own depth and velocity, projected
+ * onto the tangent plane of the cell above; down-going part: the cell's own lower edge (aux2), projected onto the
+ * tangent plane of the cell below (aux1). */
+static void rpt2_sphere(int ixy, int imp, int meqn, int mbc, int mx, const double *q, const double *asdq,
+                        double *bmasdq, double *bpasdq, const double *par)
+{
+    const int maux = orc_maux1d;
+    const double *aux1 = orc_auxb1d, *aux2 = orc_aux1d, *aux3 = orc_auxa1d;
+    const double g = par[0];
+    const double dx = (ixy == 1) ? par[1] : par[2];
+    const int ioff = (ixy == 1) ? 7 : 1;
+#define AXN(arr, ma, i) arr[((ma)-1) + maux * IX(i)]
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const int i1 = i - 2 + imp;
+        for (int up = 1; up >= 0; up--) {
+            const double *ae = up ? aux3 : aux2;       /* edge geometry */
+            const double *ap = up ? aux3 : aux1;       /* tangent plane of the receiving cell */
+            double enx = AXN(ae, ioff + 1, i1), eny = AXN(ae, ioff + 2, i1), enz = AXN(ae, ioff + 3, i1);
+            double etx = AXN(ae, ioff + 4, i1), ety = AXN(ae, ioff + 5, i1), etz = AXN(ae, ioff + 6, i1);
+            const double gamma = sqrt(etx * etx + ety * ety + etz * etz);
+            etx = etx / gamma; ety = ety / gamma; etz = etz / gamma;
+            const double h = A2(q, 1, i1);
+            const double u = (enx * A2(q, 2, i1) + eny * A2(q, 3, i1) + enz * A2(q, 4, i1)) / h;
+            const double v = (etx * A2(q, 2, i1) + ety * A2(q, 3, i1) + etz * A2(q, 4, i1)) / h;
+            const double a = sqrt(g * h);
+            const double delta1 = A2(asdq, 1, i);
+            const double delta2 = enx * A2(asdq, 2, i) + eny * A2(asdq, 3, i) + enz * A2(asdq, 4, i);
+            const double delta3 = etx * A2(asdq, 2, i) + ety * A2(asdq, 3, i) + etz * A2(asdq, 4, i);
+            const double a1 = ((u + a) * delta1 - delta2) * (0.50 / a);
+            const double a2 = -v * delta1 + delta3;
+            const double a3 = (-(u - a) * delta1 + delta2) * (0.50 / a);
+            double wb[5][4], sb[4];
+            wb[1][1] = a1;
+            wb[2][1] = a1 * (u - a) * enx + a1 * v * etx;
+            wb[3][1] = a1 * (u - a) * eny + a1 * v * ety;
+            wb[4][1] = a1 * (u - a) * enz + a1 * v * etz;
+            sb[1] = (u - a) * gamma / dx;
+            wb[1][2] = 0.0;
+            wb[2][2] = a2 * etx;
+            wb[3][2] = a2 * ety;
+            wb[4][2] = a2 * etz;
+            sb[2] = u * gamma / dx;
+            wb[1][3] = a3;
+            wb[2][3] = a3 * (u + a) * enx + a3 * v * etx;
+            wb[3][3] = a3 * (u + a) * eny + a3 * v * ety;
+            wb[4][3] = a3 * (u + a) * enz + a3 * v * etz;
+            sb[3] = (u + a) * gamma / dx;
+            double *out = up ? bpasdq : bmasdq;
+            for (int m = 1; m <= 4; m++) {
+                double acc = 0.0;
+                for (int mw = 1; mw <= 3; mw++)
+                    acc = acc + (up ? dmax(sb[mw], 0.0) : dmin(sb[mw], 0.0)) * wb[m][mw];
+                A2(out, m, i) = acc;
+            }
+            const double erx = AXN(ap, 14, i1), ery = AXN(ap, 15, i1), erz = AXN(ap, 16, i1);
+            const double bn = erx * A2(out, 2, i) + ery * A2(out, 3, i) + erz * A2(out, 4, i);
+            A2(out, 2, i) = A2(out, 2, i) - bn * erx;
+            A2(out, 3, i) = A2(out, 3, i) - bn * ery;
+            A2(out, 4, i) = A2(out, 4, i) - bn * erz;
+        }
+    }
+#undef AXN
+}
+
+/* qcor.f:1-72 (test/shallow_sphere/qcor.f): correction that keeps the scheme conservative on the sphere; aux2 and
+ * q1d are the current slice.  qc[1..4]. */
+static void sphere_qcor(int ixy, int i, const double *aux, int maux, const double *q, int meqn, int mbc,
+                        const double *par, double *qc)
+{
+#define AXQ(ma, i) aux[((ma)-1) + maux * IX(i)]
+    const double g = par[0];
+    const int in = (ixy == 1) ? 2 : 8;
+    const double dy = (ixy == 1) ? par[2] : par[1];
+    const double etxl = AXQ(in + 3, i), etyl = AXQ(in + 4, i), etzl = AXQ(in + 5, i);
+    const double gammal = sqrt(etxl * etxl + etyl * etyl + etzl * etzl) / dy;
+    const double enxl = AXQ(in, i) * gammal, enyl = AXQ(in + 1, i) * gammal, enzl = AXQ(in + 2, i) * gammal;
+    const double etxr = AXQ(in + 3, i + 1), etyr = AXQ(in + 4, i + 1), etzr = AXQ(in + 5, i + 1);
+    const double gammar = sqrt(etxr * etxr + etyr * etyr + etzr * etzr) / dy;
+    const double enxr = AXQ(in, i + 1) * gammar, enyr = AXQ(in + 1, i + 1) * gammar, enzr = AXQ(in + 2, i + 1) * gammar;
+    const double q1 = A2(q, 1, i), q2 = A2(q, 2, i), q3 = A2(q, 3, i), q4 = A2(q, 4, i);
+    qc[1] = (enxr - enxl) * q2 + (enyr - enyl) * q3 + (enzr - enzl) * q4;
+    qc[2] = (enxr - enxl) * (q2 * q2 / q1 + 0.5 * g * (q1 * q1)) + (enyr - enyl) * (q2 * q3 / q1) +
+            (enzr - enzl) * (q2 * q4 / q1);
+    qc[3] = (enxr - enxl) * (q2 * q3 / q1) + (enyr - enyl) * (q3 * q3 / q1 + 0.5 * g * (q1 * q1)) +
+            (enzr - enzl) * (q3 * q4 / q1);
+    qc[4] = (enxr - enxl) * (q2 * q4 / q1) + (enyr - enyl) * (q3 * q4 / q1) +
+            (enzr - enzl) * (q4 * q4 / q1 + 0.5 * g * (q1 * q1));
+    const double erx = AXQ(14, i), ery = AXQ(15, i), erz = AXQ(16, i);
+    const double qcn = erx * qc[2] + ery * qc[3] + erz * qc[4];
+    qc[2] = qc[2] - qcn * erx;
+    qc[3] = qc[3] - qcn * ery;
+    qc[4] = qc[4] - qcn * erz;
+#undef AXQ
+}
+/* step2qcor.f is the app's replacement of step2.f (test/shallow_sphere/Makefile:16): orc_step2 follows it when
+ * this switch is on (the capa branch then also subtracts dtdx*qc/capa, step2qcor.f:146-159,232-245). */
+static int orc_qcor_on = 0;
+void orc_set_qcor(int on) { orc_qcor_on = on; }
+
 /* 2-D acoustics normal solver, restated (third-party rpn2_acoustics.f) */
 static void rpn2_acoustics(int ixy, int meqn, int mwaves, int mbc, int mx,
                            const double *ql, const double *qr, double *wave, double *s, double *amdq,
@@ -771,6 +992,10 @@ static int rpn2_dispatch(int rp, int ixy, int meqn, int mwaves, int mbc, int mx,
         if (!orc_aux1d || orc_maux1d < 2) return -1;
         rpn2_vc_advection(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
         return 0;
+    case RP_SHALLOW_SPHERE_2D:
+        if (!orc_aux1d || orc_maux1d < 16 || meqn != 4 || mwaves != 3) return -1;
+        rpn2_sphere(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
+        return 0;
     case RP_ACOUSTICS_2D:
         rpn2_acoustics(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
         return 0;
@@ -793,6 +1018,10 @@ static int rpt2_dispatch(int rp, int ixy, int meqn, int mbc, int mx, const doubl
     case RP_VC_ADVECTION_2D:
         if (!orc_aux1d || !orc_auxa1d) return -1;
         rpt2_vc_advection(ixy, imp, meqn, mbc, mx, asdq, bmasdq, bpasdq);
+        return 0;
+    case RP_SHALLOW_SPHERE_2D:
+        if (!orc_aux1d || !orc_auxb1d || !orc_auxa1d) return -1;
+        rpt2_sphere(ixy, imp, meqn, mbc, mx, q, asdq, bmasdq, bpasdq, par);
         return 0;
     case RP_ADVECTION_2D:
         rpt2_advection(ixy, meqn, mbc, mx, asdq, bmasdq, bpasdq, par);
@@ -1065,6 +1294,13 @@ int orc_step2(int rp, const double *par, int fwave, int maxm, int meqn, int mwav
                     Q3(qnew, m, i, j + 1) = Q3(qnew, m, i, j + 1) +
                                             dtdy * GADD(m, 2, i) / AUX3(mcapa, i, j + 1);
                 }
+            if (orc_qcor_on)        /* step2qcor.f:146-159: qnew(m,i,j) -= dtdx*qc(m)/capa, right after the cell's own update */
+                for (int i = 1; i <= mx; i++) {
+                    double qc[5];
+                    sphere_qcor(1, i, aux1d, maux, q1d, meqn, mbc, par, qc);
+                    for (int m = 1; m <= meqn; m++)
+                        Q3(qnew, m, i, j) = Q3(qnew, m, i, j) - dtdx * qc[m] / AUX3(mcapa, i, j);
+                }
         }
     }
 
@@ -1105,6 +1341,13 @@ int orc_step2(int rp, const double *par, int fwave, int maxm, int meqn, int mwav
                                             dtdx * GADD(m, 1, j) / AUX3(mcapa, i - 1, j);
                     Q3(qnew, m, i + 1, j) = Q3(qnew, m, i + 1, j) +
                                             dtdx * GADD(m, 2, j) / AUX3(mcapa, i + 1, j);
+                }
+            if (orc_qcor_on)        /* step2qcor.f:232-245 */
+                for (int j = 1; j <= my; j++) {
+                    double qc[5];
+                    sphere_qcor(2, j, aux1d, maux, q1d, meqn, mbc, par, qc);
+                    for (int m = 1; m <= meqn; m++)
+                        Q3(qnew, m, i, j) = Q3(qnew, m, i, j) - dtdy * qc[m] / AUX3(mcapa, i, j);
                 }
         }
     }

@@ -76,6 +76,33 @@ __device__ __forceinline__ void cfl_publish(unsigned long long *word, double v) 
     }
 }
 
+// Courant number of one interface (flux2.f:109-117): max over the waves of dtdx(i)*s and -dtdx(i-1)*s.
+// Without a capacity function dtdx is one positive number for the whole grid, and rounding is monotone:
+//     max_k fl(d*s_k) = fl(d * max_k s_k)   and   max(fl(d*s), fl(-d*s)) = fl(d*|s|),
+// so the running maximum is kept over |s| alone (one v_max_f64 with |.| per wave instead of two multiplies
+// and two maxima) and multiplied by dt/dx ONCE per wavefront, in cfl_value() below: the same bits.
+// With a capacity function dtdx differs from cell to cell and the reference's expression is kept.
+// A NaN speed is ignored either way (v_max_f64 returns the other operand).
+template <bool CAPA, int MWAVES>
+__device__ __forceinline__ void cfl_accumulate(const double (&s)[MWAVES], double dtdx_c, double dtdx_l, bool cfl_ok,
+                                               double &cflmax) {
+    if constexpr (CAPA) {
+        if (cfl_ok) {
+#pragma unroll
+            for (int mw = 0; mw < MWAVES; mw++) cflmax = dmax(dmax(cflmax, dtdx_c * s[mw]), -dtdx_l * s[mw]);
+        }
+    } else {
+        double m = fabs(s[0]);
+#pragma unroll
+        for (int mw = 1; mw < MWAVES; mw++) m = dmax(m, fabs(s[mw]));
+        if (cfl_ok) cflmax = dmax(cflmax, m);
+    }
+}
+// what a kernel publishes: the accumulated maximum itself (CAPA) or dt/dx times the largest |s|
+template <bool CAPA> __device__ __forceinline__ double cfl_value(double cflmax, double dtd) {
+    return CAPA ? cflmax : dtd * cflmax;
+}
+
 // ---- the per-lane core ------------------------------------------------------------------
 // q      : this lane's cell
 // dtdx_c : dtdx1d of this lane's cell (dt/dx, divided by capa when present)
@@ -113,7 +140,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
     // that (q + 0).  Only the wave speeds are needed, for the Courant number (flux2.f:109-117); they come
     // from the same Roe average the full solve uses.  Wave-uniform branch; a non-finite speed (unphysical
     // state) takes the full path.  PCL_TUNE_ABLATE bit 4 switches the shortcut off (tools/kbench.py).
-    {
+    if constexpr (!FWAVE) {   // f-waves over varying aux are non-zero even for equal q: no shortcut there
         const bool lane0 = (threadIdx.x & (WAVE - 1)) == 0;   // lane 0 has no left cell
         // first component first: where the state varies at all, one compare per lane settles it
         bool same = !(a.ablate & 16) && __all(lane0 || cL.q[0] == cR.q[0]);
@@ -129,11 +156,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
 #pragma unroll
             for (int mw = 0; mw < MWAVES; mw++) finite = finite && (s[mw] - s[mw] == 0.0);
             if (__all(finite || (threadIdx.x & (WAVE - 1)) == 0)) {
-                if (cfl_ok && !(a.ablate & 8)) {
-#pragma unroll
-                    for (int mw = 0; mw < MWAVES; mw++)
-                        cflmax = dmax(dmax(cflmax, dtdx_c * s[mw]), -dtdx_l * s[mw]);
-                }
+                if (!(a.ablate & 8)) cfl_accumulate<CAPA, MWAVES>(s, dtdx_c, dtdx_l, cfl_ok, cflmax);
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) {
                     if constexpr (TRANS) { qn[m] = 0.0; df[m] = 0.0; g1[m] = 0.0; g2[m] = 0.0; }  // the slice's pieces
@@ -146,11 +169,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
     RP::template solve<IXY>(cL, cR, a.par, wave, s, amdq, apdq);
 
     // Courant number, flux2.f:109-117
-    if (cfl_ok && !(a.ablate & 8)) {
-#pragma unroll
-        for (int mw = 0; mw < MWAVES; mw++)
-            cflmax = dmax(dmax(cflmax, dtdx_c * s[mw]), -dtdx_l * s[mw]);
-    }
+    if (!(a.ablate & 8)) cfl_accumulate<CAPA, MWAVES>(s, dtdx_c, dtdx_l, cfl_ok, cflmax);
 
     double fadd[MEQN], cq[MEQN];
 #pragma unroll
@@ -576,7 +595,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
         }
     }
     if constexpr (TRANS) {
-        cfl_publish(a.cfl, cflmax);
+        cfl_publish(a.cfl, cfl_value<CAPA>(cflmax, a.dtd));
         return;
     }
     __syncthreads();
@@ -612,7 +631,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             if (inner ? (al >= HALO && al < T::ALONG - HALO) : true) put(al, ac);
         }
     }
-    cfl_publish(a.cfl, cflmax);
+    cfl_publish(a.cfl, cfl_value<CAPA>(cflmax, a.dtd));
 }
 
 // ---- unsplit algorithm without scratch planes (no capacity function) ---------------------------------
@@ -674,7 +693,7 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, i
             a.qout[m * a.plane + g] = v;
         }
     }
-    cfl_publish(a.cfl, cflmax);
+    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
 }
 
 // y phase: qx = result of the x phase (read and overwritten cell by cell), a.qin = qold
@@ -747,7 +766,7 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
             }
         }
     }
-    cfl_publish(a.cfl, cflmax);
+    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
 }
 
 // ---- unsplit algorithm: sum the slice pieces into qnew in the reference's order ----------------
@@ -914,7 +933,7 @@ __global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac,
             if (inner ? (al >= HALO && al < ALONG - HALO) : true) put(al, threadIdx.x % AC);
         }
     }
-    cfl_publish(a.cfl, cflmax);
+    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
 }
 
 }  // namespace PCL_NS

@@ -991,6 +991,10 @@ int pcl_select(pcl_solver *s, int reg) {
 static int sharp_passes(pcl_solver *s, double dt, int rk_op, const double *ra, const double *rb, double *rd,
                         double ca, double cb, double cc) {
     std::string err;
+    // the fused store phase dereferences all three operands whenever rk_op != 0 (sharpclaw.hpp): a null one is a
+    // memory fault at address 0 on the device, so it is refused here
+    if (rk_op && (!ra || !rb || !rd)) return fail(PCL_EINVAL, "fused RK stage: null register operand");
+    if (!cur(s) || !s->sreg[PCL_REG_DQ]) return fail(PCL_ESTATE, "SharpClaw registers not allocated");
     for (int ids = 1; ids <= s->cfg.ndim; ids++) {
         SweepLaunch l;
         l.a = make_args(s, cur(s), s->sreg[PCL_REG_DQ], ids, dt);
@@ -1226,9 +1230,35 @@ int pcl_comm_unique_id(char uid[128]) {
     return PCL_OK;
 }
 
+int pcl_comm_check(int nranks, int rank, const int neighbors[8]) {
+    if (!neighbors) return fail(PCL_EINVAL, "null argument");
+    if (nranks < 1) return fail(PCL_EINVAL, "pcl_comm_init: nranks must be >= 1 (got " + std::to_string(nranks) + ")");
+    if (rank < 0 || rank >= nranks)
+        return fail(PCL_EINVAL, "pcl_comm_init: rank " + std::to_string(rank) + " outside 0.." + std::to_string(nranks - 1));
+    static const char *dirs[8] = {"W", "E", "S", "N", "SW", "SE", "NW", "NE"};
+    for (int d = 0; d < 8; d++) {
+        const int nb = neighbors[d];
+        if (nb < -1 || nb >= nranks)
+            return fail(PCL_EINVAL, std::string("pcl_comm_init: neighbour ") + dirs[d] + " = " + std::to_string(nb) +
+                                        " is not a rank of this communicator (0.." + std::to_string(nranks - 1) + ", or -1)");
+    }
+    // A block is its own neighbour only across a periodic dimension that it spans alone; then BOTH faces of that
+    // dimension wrap onto it.  One face = self and the other not means the caller's neighbour table is wrong.
+    if ((neighbors[0] == rank) != (neighbors[1] == rank))
+        return fail(PCL_EINVAL, "pcl_comm_init: W/E neighbours: a block that wraps onto itself does so on both faces");
+    if ((neighbors[2] == rank) != (neighbors[3] == rank))
+        return fail(PCL_EINVAL, "pcl_comm_init: S/N neighbours: a block that wraps onto itself does so on both faces");
+    return PCL_OK;
+}
+
 int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], const int neighbors[8]) {
     if (!s || !uid || !neighbors) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.ndim < 2) return fail(PCL_EINVAL, "halo exchange is implemented for 2-D blocks and 3-D blocks decomposed over (y, z)");
+    // argument validation BEFORE anything reaches RCCL (whose own diagnostics for these mistakes is a bare
+    // "invalid usage" from ncclCommInitRank)
+    if (int rc = pcl_comm_check(nranks, rank, neighbors)) return rc;
+    if (nranks > 1 && getenv("PCL_FORCE_DEVICE"))
+        return fail(PCL_EINVAL, "pcl_comm_init: PCL_FORCE_DEVICE pins every rank to one GPU; RCCL needs one device per rank");
     HIP_TRY(hipSetDevice(s->cfg.device));
     std::string err;
     const int nmax = s->cfg.meqn > s->cfg.maux ? s->cfg.meqn : s->cfg.maux;

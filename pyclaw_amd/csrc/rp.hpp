@@ -49,6 +49,27 @@ __device__ __forceinline__ double dsqrt(double x) {
     g = __builtin_fma(d, h, g);
     return __builtin_amdgcn_class(x, 0x260) ? x : g;  // +-0, +inf pass through
 }
+// The same sequence without the +-0 / +inf pass-through (a v_cmp_class and two v_cndmask): for arguments that are
+// strictly positive and finite in every physical state -- a density, the squared Roe sound speed.  (For 0 or inf
+// it returns NaN where sqrt() returns 0 / inf: such a state is already outside the solver's domain, the very next
+// operations divide by the root.)
+// It also hands out the iteration's by-product h ~ 1/(2 sqrt x) (relative error <= 2^-47.8 measured over 10^6
+// arguments, tools/ubench/seed_accuracy.hip): a far better reciprocal seed than v_rcp_f64 (2^-24), see
+// Recip::seeded below.
+struct SqrtH { double g, h; };
+__device__ __forceinline__ SqrtH dsqrt_pos_h(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return SqrtH{__builtin_fma(d, h, g), h};
+}
+__device__ __forceinline__ double dsqrt_pos(double x) { return dsqrt_pos_h(x).g; }
 
 // ---- division ------------------------------------------------------------------------------
 // hipcc expands an IEEE f64 division into 2 v_div_scale, v_rcp_f64, 4 fma (Newton on the
@@ -67,6 +88,18 @@ __device__ __forceinline__ double dsqrt(double x) {
 // squares that can legitimately underflow, keeps the full IEEE division in exact mode.
 struct Recip {
     double d, r;
+    // From a seed y0 that is already 1/den to a few 2^-48 (a by-product of a square root of the same quantity, or
+    // the square of such a reciprocal): ONE Newton step lands within an ulp, like the two steps from v_rcp_f64's
+    // 2^-24 seed below -- no quarter-rate instruction, two fma instead of five instructions.  The quotients stay
+    // correctly rounded for the same reason (Markstein; what matters is |r*den - 1| <~ 2^-52).
+    __device__ __forceinline__ static Recip seeded(double den, double y0) {
+        Recip x;
+        x.d = den;
+        const double e = __builtin_fma(-den, y0, 1.0);
+        x.r = __builtin_fma(y0, e, y0);
+        return x;
+    }
+    __device__ __forceinline__ Recip() {}
     __device__ __forceinline__ explicit Recip(double den) : d(den) {
         double y = __builtin_amdgcn_rcp(den);
         double e = __builtin_fma(-den, y, 1.0);
@@ -680,8 +713,8 @@ struct Euler5 {
         double qu_rs;   // q(mu)/sqrt(rho)                 rpn2:95
         double qv_rs;   // q(mv)/sqrt(rho)                 rpn2:96
         double h_rs;    // (E+p)/sqrt(rho)                 rpn2:97-98
-        double c;       // sqrt(gamma*p/rho)               rpn2:213,262
-        double un;      // q(mu)/rho                       rpn2:214,263
+        double smc;     // q(mu)/rho - sqrt(gamma*p/rho)   rpn2:213-215  (u - c of this cell: the 1-wave check on its right edge)
+        double spc;     // q(mu)/rho + sqrt(gamma*p/rho)   rpn2:262-264  (u + c: the 3-wave check on its left edge)
     };
     // wave(m,mw) sparsity, rpn2:124-163
     template <int IXY> __device__ static constexpr bool nz(int mw, int m) {
@@ -694,17 +727,21 @@ struct Euler5 {
         const double gamma = par.v[0], gamma1 = par.v[1];
         Cell c;
         for (int m = 0; m < 5; m++) c.q[m] = q[m];
-        c.rs = dsqrt(q[0]);
-        const Recip by_rho(q[0]), by_rs(c.rs);
+        const SqrtH sr = dsqrt_pos_h(q[0]);
+        c.rs = sr.g;
+        // 1/sqrt(rho) seeded with 2h, 1/rho with its square: same quotients as Recip(q[0]), Recip(c.rs)
+        const Recip by_rs = Recip::seeded(c.rs, sr.h + sr.h);
+        const Recip by_rho = Recip::seeded(q[0], by_rs.r * by_rs.r);
         c.p = gamma1 * (q[3] - by_rho.div(0.5 * (q[1] * q[1] + q[2] * q[2])));
         c.qu_rs = by_rs.div(q[mu]);
         c.qv_rs = by_rs.div(q[mv]);
         c.h_rs = by_rs.div(q[3] + c.p);
-        c.c = dsqrt(by_rho.div(gamma * c.p));
-        c.un = by_rho.div(q[mu]);
+        const double cc = dsqrt(by_rho.div(gamma * c.p)), un = by_rho.div(q[mu]);
+        c.smc = un - cc;
+        c.spc = un + cc;
         return c;
     }
-    struct Roe { double u, v, enth, a, g1a2, euv, u2v2; };
+    struct Roe { double u, v, enth, a, g1a2, euv, u2v2; Recip by_2a; };
     __device__ static __forceinline__ Roe roe(const Cell &L, const Cell &R, double gamma1) {
         Roe r;
         const Recip by_rhsq2(L.rs + R.rs);
@@ -713,8 +750,11 @@ struct Euler5 {
         r.enth = by_rhsq2.div(L.h_rs + R.h_rs);
         r.u2v2 = r.u * r.u + r.v * r.v;
         const double a2 = gamma1 * (r.enth - .5 * r.u2v2);
-        r.a = dsqrt(a2);
-        r.g1a2 = fdiv(gamma1, a2);
+        const SqrtH sa = dsqrt_pos_h(a2);
+        r.a = sa.g;
+        // 1/(2a) seeded with h (the a4 / transverse a4 quotients), 1/a^2 with 4*(1/(2a))^2
+        r.by_2a = Recip::seeded(2.0 * r.a, sa.h);
+        r.g1a2 = Recip::seeded(a2, 4.0 * (r.by_2a.r * r.by_2a.r)).div(gamma1);
         r.euv = r.enth - r.u2v2;
         return r;
     }
@@ -737,7 +777,7 @@ struct Euler5 {
         const double delta4 = R.q[3] - L.q[3];
         const double a3 = r.g1a2 * (r.euv * delta1 + u * delta2 + v * delta3 - delta4);
         const double a2 = delta3 - v * delta1;
-        const double a4 = fdiv(delta2 + (a - u) * delta1 - a * a3, 2.0 * a);
+        const double a4 = r.by_2a.div(delta2 + (a - u) * delta1 - a * a3);
         const double a1 = delta1 - a3 - a4;
 
         wave[0][0] = a1; wave[0][mu] = a1 * (u - a); wave[0][mv] = a1 * v;
@@ -752,7 +792,7 @@ struct Euler5 {
         wave[4][4] = R.q[4] - L.q[4]; s[4] = u;
 
         // ---- entropy fix (rpn2:205-286).  The early exits of the Fortran become flags.
-        const double s0 = L.un - L.c;                       // u-c in left state
+        const double s0 = L.smc;                            // u-c in left state
         const bool all_right = (s0 >= 0.0) && (s[0] > 0.0); // rpn2:217
         {
             const double rho1 = L.q[0] + wave[0][0];
@@ -778,7 +818,7 @@ struct Euler5 {
                 if (nz<IXY>(2, m)) amdq[m] = amdq[m] + s[2] * wave[2][m];
                 if (nz<IXY>(4, m)) amdq[m] = amdq[m] + s[4] * wave[4][m];
             }
-            const double s3 = R.un + R.c;                    // u+c in right state
+            const double s3 = R.spc;                         // u+c in right state
             const double rho2 = R.q[0] - wave[3][0];
             const double rhou2 = R.q[mu] - wave[3][mu];
             const double rhov2 = R.q[mv] - wave[3][mv];
@@ -823,7 +863,7 @@ struct Euler5 {
         const double u = r.u, v = r.v, enth = r.enth, a = r.a;
         const double a3 = r.g1a2 * (r.euv * asdq[0] + u * asdq[mu] + v * asdq[mv] - asdq[3]);
         const double a2 = asdq[mu] - u * asdq[0];
-        const double a4 = fdiv(asdq[mv] + (a - v) * asdq[0] - a * a3, 2.0 * a);
+        const double a4 = r.by_2a.div(asdq[mv] + (a - v) * asdq[0] - a * a3);
         const double a1 = asdq[0] - a3 - a4;
         double wb[4][5], sb[4];
         wb[0][0] = a1; wb[0][mu] = a1 * u; wb[0][mv] = a1 * (v - a);

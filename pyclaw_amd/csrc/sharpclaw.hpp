@@ -234,6 +234,14 @@ __global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, i
                 // last pass of a stage: the RK combination of sharpclaw.py:168-206 (same expressions as rk_kernel).
                 // Branch-free on purpose: with a scalar branch per op the ROCm 7.2 backend left the store base
                 // of the op-5 path undefined in the 1-D instantiation (memory fault at address 0).
+#ifdef PCL_SHARP_BRANCHY   /* diagnostic build only: the form that faulted in round 1 */
+                switch (a.rk_op) {
+                case 0: a.qout[at] = dq; break;
+                case 1: a.rk_d[at] = a.rk_a[at] + dq / a.rk_ca; break;
+                case 2: a.rk_d[at] = a.rk_ca * a.rk_a[at] + a.rk_cb * (a.rk_b[at] + dq); break;
+                case 5: a.rk_d[at] = a.rk_a[at] + a.rk_cb * a.rk_b[at] + a.rk_cc * dq; break;
+                }
+#else
                 double r = dq;
                 if (a.rk_op != 0) {
                     const double av = a.rk_a[at], bv = a.rk_b[at];
@@ -244,6 +252,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, i
                 }
                 double *dst = a.rk_op != 0 ? a.rk_d : a.qout;
                 dst[at] = r;
+#endif
             }
         }
     }

@@ -6,47 +6,187 @@ and ``getRanges()`` (src/petclaw/state.py:191-232).  The data path (ghost-cell e
 all-reduce) is RCCL called from libpyclaw_amd on the solver's HIP stream (csrc/halo.hpp);
 this module only does the host-side control plane:
 
-* rank / world size from the launcher's environment (``RANK``, ``WORLD_SIZE``, ``LOCAL_RANK``),
+* rank / world size from the launcher's environment (``RANK``, ``WORLD_SIZE``, ``LOCAL_RANK`` --
+  what ``torch.distributed.run``, ``mpirun`` wrappers or a plain shell loop export),
 * the px x py processor grid (same rule as PETSc's DMDA: px ~ sqrt(size*nx/ny), then the
   nearest divisor) and the index ranges of each block,
 * the 8 neighbour ranks of a block (BOX stencil), with periodic wrap where the physical
   boundary condition is periodic,
-* a tiny key/value rendezvous to hand rank 0's ncclUniqueId to the other ranks -- done with
-  ``torch.distributed`` (gloo, CPU) because the launcher is ``torch.distributed.run``; torch
-  is imported only when WORLD_SIZE > 1 and never touches device memory here.
+* a tiny rendezvous that hands rank 0's 128-byte ncclUniqueId to the other ranks, plus barrier / max /
+  sum of a few host doubles (bench timing, output functionals).  Standard library only (one TCP
+  connection per rank to rank 0): **no PyTorch anywhere in the package**, so ``librccl`` resolves to
+  /opt/rocm's copy, not to a wheel's bundled one.
+
+Rendezvous: rank 0 listens on an ephemeral port and publishes ``host:port`` in a small file whose name is
+derived from ``MASTER_ADDR``/``MASTER_PORT`` (+ ``TORCHELASTIC_RUN_ID``) under ``PCL_RDZV_DIR`` (default
+``/tmp``: ranks of one node, which is what the benchmark contract launches).  The launcher's own port is
+never bound here -- ``torch.distributed.run`` keeps its agent store on it.  For several nodes either point
+``PCL_RDZV_DIR`` at a shared directory or set ``PCL_RDZV_ADDR=host:port`` (rank 0 binds exactly that).
 """
+import atexit
+import json
 import math
 import os
+import socket
+import struct
+import time
 
 # direction order shared with csrc/halo.hpp
 W, E, S, N, SW, SE, NW, NE = range(8)
 _OFFSETS = [(-1, 0), (1, 0), (0, -1), (0, 1), (-1, -1), (1, -1), (-1, 1), (1, 1)]
 
-_state = {"rank": 0, "size": 1, "initialized": False, "dist": None}
+_state = {"rank": 0, "size": 1, "initialized": False, "group": None}
+
+_MAGIC = "pyclaw_amd-rdzv-1"
+_TIMEOUT = float(os.environ.get("PCL_RDZV_TIMEOUT", "300"))
 
 
-def init(backend="gloo"):
-    """Join the process group described by the environment (no-op for a single process)."""
+def _send(sock, obj):
+    raw = json.dumps(obj).encode("utf-8")
+    sock.sendall(struct.pack("!I", len(raw)) + raw)
+
+
+def _recv(sock):
+    def exactly(n):
+        buf = b""
+        while len(buf) < n:
+            chunk = sock.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("pyclaw_amd.parallel: peer closed the rendezvous connection")
+            buf += chunk
+        return buf
+    (n,) = struct.unpack("!I", exactly(4))
+    return json.loads(exactly(n).decode("utf-8"))
+
+
+class _Group(object):
+    """Star-shaped process group: every rank keeps one TCP connection to rank 0.  The only primitive is
+    allgather of a small JSON value (floats survive exactly: json writes repr()); barrier, broadcast and the
+    reductions are built on it and reduce in rank order, so every rank computes the same bits."""
+
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+        self.peers = []          # rank 0: sockets of ranks 1..size-1 (index r-1)
+        self.up = None           # other ranks: socket to rank 0
+        self.addr_file = None
+        explicit = os.environ.get("PCL_RDZV_ADDR")
+        if explicit:
+            host, port = explicit.rsplit(":", 1)
+            port = int(port)
+        else:
+            host, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), 0
+            tag = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
+                                os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+            tag = "".join(c if c.isalnum() or c in "._-" else "_" for c in tag)
+            self.addr_file = os.path.join(os.environ.get("PCL_RDZV_DIR", "/tmp"), "pyclaw_amd_rdzv_%s.addr" % tag)
+        if rank == 0:
+            self._serve(host, port, explicit is not None)
+        else:
+            self._join(host, port, explicit is not None)
+
+    def _serve(self, host, port, explicit):
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        try:
+            srv.bind((host, port))
+        except OSError:
+            srv.bind(("0.0.0.0", port))       # MASTER_ADDR may be a name that is not a local interface
+        srv.listen(self.size)
+        port = srv.getsockname()[1]
+        if not explicit:
+            tmp = self.addr_file + ".%d" % os.getpid()
+            with open(tmp, "w") as f:
+                f.write("%s:%d:%d" % (host, port, os.getpid()))
+            os.replace(tmp, self.addr_file)      # atomic: a reader never sees a partial file
+            atexit.register(self._unlink)
+        srv.settimeout(_TIMEOUT)
+        got = {}
+        while len(got) < self.size - 1:
+            conn, _ = srv.accept()
+            conn.settimeout(_TIMEOUT)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            hello = _recv(conn)
+            ok = (isinstance(hello, dict) and hello.get("magic") == _MAGIC and hello.get("size") == self.size
+                  and isinstance(hello.get("rank"), int) and 0 < hello["rank"] < self.size
+                  and hello["rank"] not in got)
+            _send(conn, {"ok": bool(ok)})
+            if ok:
+                got[hello["rank"]] = conn
+            else:
+                conn.close()               # a stray client (or a rank of another job): keep waiting
+        srv.close()
+        self.peers = [got[r] for r in range(1, self.size)]
+
+    def _join(self, host, port, explicit):
+        deadline = time.time() + _TIMEOUT
+        last = None
+        while time.time() < deadline:
+            try:
+                if not explicit:
+                    with open(self.addr_file) as f:
+                        h, p, _pid = f.read().strip().split(":")
+                    host, port = h, int(p)
+                sock = socket.create_connection((host, port), timeout=5.0)
+                sock.settimeout(_TIMEOUT)
+                sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                _send(sock, {"magic": _MAGIC, "rank": self.rank, "size": self.size})
+                if _recv(sock).get("ok"):
+                    self.up = sock
+                    return
+                sock.close()
+            except (OSError, ValueError, ConnectionError) as e:   # no file yet, stale file, server not up yet
+                last = e
+            time.sleep(0.05)
+        raise RuntimeError("pyclaw_amd.parallel: rank %d could not reach rank 0 within %.0f s (%s)"
+                           % (self.rank, _TIMEOUT, last))
+
+    def _unlink(self):
+        try:
+            if self.addr_file:
+                os.unlink(self.addr_file)
+        except OSError:
+            pass
+
+    def allgather(self, value):
+        if self.rank == 0:
+            vals = [value] + [_recv(c) for c in self.peers]
+            for c in self.peers:
+                _send(c, vals)
+            return vals
+        _send(self.up, value)
+        return _recv(self.up)
+
+    def close(self):
+        for c in self.peers + ([self.up] if self.up else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._unlink()
+
+
+def init(backend=None):
+    """Join the process group described by the environment (no-op for a single process).  `backend` is accepted
+    for source compatibility and ignored: the control plane is this module's own TCP rendezvous."""
     if _state["initialized"]:
         return
     size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if size > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29500")
-            dist.init_process_group(backend=backend, rank=rank, world_size=size)
-        _state["dist"] = dist
-        rank, size = dist.get_rank(), dist.get_world_size()
-    _state.update(rank=rank, size=size, initialized=True)
+    if size < 1 or rank < 0 or rank >= size:
+        raise RuntimeError("pyclaw_amd.parallel: bad RANK=%d / WORLD_SIZE=%d in the environment" % (rank, size))
+    group = _Group(rank, size) if size > 1 else None
+    _state.update(rank=rank, size=size, initialized=True, group=group)
 
 
 def shutdown():
-    dist = _state["dist"]
-    if dist is not None and dist.is_initialized():
-        dist.destroy_process_group()
-    _state.update(rank=0, size=1, initialized=False, dist=None)
+    g = _state["group"]
+    if g is not None:
+        try:
+            g.allgather(None)      # nobody closes while a peer still talks
+        except (OSError, ConnectionError):
+            pass
+        g.close()
+    _state.update(rank=0, size=1, initialized=False, group=None)
 
 
 def rank():
@@ -63,46 +203,45 @@ def local_rank():
 
 def device_ordinal():
     """HIP device of this rank: LOCAL_RANK, unless PCL_FORCE_DEVICE pins every rank to one ordinal
-    (diagnostics on a single-GPU box)."""
+    (diagnostics on a single-GPU box; pcl_comm_init refuses it for more than one rank)."""
     forced = os.environ.get("PCL_FORCE_DEVICE")
     return int(forced) if forced is not None else local_rank()
 
 
 def barrier():
-    if _state["dist"] is not None:
-        _state["dist"].barrier()
+    g = _state["group"]
+    if g is not None:
+        g.allgather(None)
 
 
 def broadcast_bytes(data, src=0):
     """Hand a small bytes object from rank src to everyone (ncclUniqueId distribution)."""
-    dist = _state["dist"]
-    if dist is None:
+    g = _state["group"]
+    if g is None:
         return data
-    box = [data]
-    dist.broadcast_object_list(box, src=src)
-    return box[0]
+    vals = g.allgather(bytes(data).hex() if g.rank == src else None)
+    return bytes.fromhex(vals[src])
 
 
 def allreduce_max_host(value):
     """Host-side max all-reduce (bench timing, CPU tests).  The solver's CFL uses RCCL."""
-    dist = _state["dist"]
-    if dist is None:
+    g = _state["group"]
+    if g is None:
         return value
-    import torch
-    t = torch.tensor([float(value)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t[0])
+    return max(float(v) for v in g.allgather(float(value)))
 
 
 def allreduce_sum_host(values):
-    """Host-side sum all-reduce of a short list (output functionals at output times)."""
-    dist = _state["dist"]
-    if dist is None:
+    """Host-side sum all-reduce of a short list (output functionals at output times); summed in rank order."""
+    g = _state["group"]
+    if g is None:
         return list(values)
-    import torch
-    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return [float(v) for v in t]
+    rows = g.allgather([float(v) for v in values])
+    out = [0.0] * len(rows[0])
+    for row in rows:
+        for k, v in enumerate(row):
+            out[k] += v
+    return out
 
 
 def proc_grid(n_global, size):

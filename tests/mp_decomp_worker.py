@@ -1,5 +1,6 @@
 """
 Worker for tests/test_parallel_cpu.py (launched by torch.distributed.run, gloo, CPU only).
+torch is TEST infrastructure here (the launcher and the host-array transport); the package itself imports none.
 
 Runs a block-decomposed classic dim-split (or unsplit) computation and checks DECOMPOSITION
 INVARIANCE: the gathered result must equal the serial run bit for bit (the reference asserts
@@ -230,8 +231,17 @@ def checkpoint_case(outdir):
 def main():
     case = sys.argv[1]
     nsteps = int(sys.argv[2])
-    parallel.init("gloo")
+    # the TEST's transport for host arrays: gloo (torch.distributed), set up here.  The product's control plane
+    # (pyclaw_amd.parallel: rendezvous, barrier, max/sum of host scalars) is its own stdlib TCP group and runs
+    # beside it -- both are exercised by every case.
+    dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    parallel.init()
     rank, size = parallel.rank(), parallel.world_size()
+    assert (rank, size) == (dist.get_rank(), dist.get_world_size())
+    # broadcast_bytes is what carries the 128-byte ncclUniqueId in a GPU run
+    token = parallel.broadcast_bytes(bytes(range(128)) if rank == 0 else None, src=0)
+    assert token == bytes(range(128))
+    assert parallel.allreduce_sum_host([1.0, float(rank)]) == [float(size), size * (size - 1) / 2.0]
     if case.startswith("checkpoint:"):
         checkpoint_case(case.split(":", 1)[1])
     if case == "acoustics3d":

@@ -25,7 +25,16 @@ template <int OP> __global__ void k(double *out, int iters, double seed) {
     else if (OP == 7) { int lo = __double2loint(v); lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true); v = __hiloint2double(__double2hiint(v), lo); } \
     else if (OP == 8) asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(v) : "v"(b) : "vcc"); \
     else if (OP == 9) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(*(int*)&v) : "v"(3) : );     \
-    else if (OP == 10) asm volatile("v_div_fmas_f64 %0, %0, %1, %1" : "+v"(v) : "v"(b));
+    else if (OP == 10) asm volatile("v_div_fmas_f64 %0, %0, %1, %1" : "+v"(v) : "v"(b));             \
+    else if (OP == 11) asm volatile("v_mov_b64 %0, %1" : "=v"(v) : "v"(b));                             \
+    else if (OP == 12) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(v), "v"(b) : "vcc");             \
+    else if (OP == 13) asm volatile("v_min_f64 %0, %0, %1" : "+v"(v) : "v"(b));                         \
+    else if (OP == 14) asm volatile("v_mov_b32 %0, %1" : "=v"(*(int*)&v) : "v"(3));                     \
+    else if (OP == 15) asm volatile("v_sqrt_f64 %0, %0" : "+v"(v));                                     \
+    else if (OP == 16) asm volatile("v_cmp_class_f64 vcc, %0, %1" : : "v"(v), "v"(3) : "vcc");          \
+    else if (OP == 17) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(v) : "v"(b));                     \
+    else if (OP == 18) asm volatile("v_add_f64 %0, |%0|, -%1" : "+v"(v) : "v"(c));                      \
+    else if (OP == 19) asm volatile("v_pk_mov_b32 %0, %1, %1" : "=v"(v) : "v"(b));
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
     }
@@ -56,10 +65,13 @@ template <int OP> void run(const char *name, int waves_per_simd) {
 }
 
 int main() {
-    for (int w : {1, 4}) {
+    for (int w : {1, 2, 4}) {
         run<0>("v_fma_f64", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<3>("v_rcp_f64", w);
         run<4>("v_rsq_f64", w); run<5>("v_div_fixup_f64", w); run<6>("v_max_f64", w); run<7>("v_mov_dpp", w);
         run<8>("v_div_scale_f64", w); run<9>("v_cndmask_b32", w); run<10>("v_div_fmas_f64", w);
+        run<11>("v_mov_b64", w); run<12>("v_cmp_lt_f64", w); run<13>("v_min_f64", w); run<14>("v_mov_b32", w);
+        run<15>("v_sqrt_f64", w); run<16>("v_cmp_class_f64", w); run<17>("v_fma_f64 asm", w); run<18>("v_add_f64 mods", w);
+        run<19>("v_pk_mov_b32", w);
     }
     return 0;
 }
