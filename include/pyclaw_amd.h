@@ -59,6 +59,9 @@ extern "C" {
 #define PCL_RP_SHALLOW_2D 13    /* rpn2/rpt2_shallow_roe_with_efix.f  cparam: g            */
 #define PCL_RP_VC_ACOUSTICS_2D 14 /* rpn2/rpt2_vc_acoustics.f; aux(1)=Z, aux(2)=c */
 #define PCL_RP_VC_ADVECTION_2D 15 /* rpn2/rpt2_vc_advection.f; aux(1)=u at the left edge, aux(2)=v at the bottom edge */
+#define PCL_RP_SHALLOW_SPHERE_2D 16 /* rpn2/rpt2_shallow_sphere.f (apps/shallow-sphere/Makefile:7); common /sw/ g + comxyt dxcom,dycom */
+                                    /* -> rp_params g, dx, dy; aux = the 16 components of apps/shallow-sphere/setaux.f:10-25;      */
+                                    /* the unsplit step follows the app's step2qcor.f (conservation fix qcor.f) instead of step2.f */
 #define PCL_RP_VC_ACOUSTICS_3D 20 /* rpn3_vc_acoustics.f (test/acoustics/3d/Makefile); aux(1)=Z, aux(2)=c; dim-split only */
 
 /* boundary condition types = pyclaw.BC (src/pyclaw/solver.py:17-23) */
@@ -66,6 +69,10 @@ extern "C" {
 #define PCL_BC_OUTFLOW 1
 #define PCL_BC_PERIODIC 2
 #define PCL_BC_REFLECTING 3
+/* not a pyclaw.BC value: the sphere app's custom y boundary (qbc_lower_y / qbc_upper_y,
+ * apps/shallow-sphere/shallow_4_Rossby_Haurwitz_wave.py:295-313): ghost row j mirrors interior row 2*mbc-1-j with the
+ * x index reversed over the whole ghosted width.  Accepted by pcl_bc for idim = 1. */
+#define PCL_BC_SPHERE_MIRROR 4
 
 /* arithmetic mode */
 #define PCL_MATH_EXACT 0 /* no FMA contraction, IEEE divide/sqrt: bit-identical to the  */
@@ -213,6 +220,9 @@ int pcl_restore(pcl_solver *s);
  * id 1: Euler radial-symmetry source, 2-stage RK (test/euler/2d/shockbubble.py:59-94);
  *       aux[0] = radial coordinate; params = {gamma1, ndim}. */
 #define PCL_SRC_EULER_RADIAL 1
+/* id 2: Coriolis force of the shallow-water-on-the-sphere app, apps/shallow-sphere/src2.f:43-146 (projection onto the
+ *       tangent plane, 4-stage RK, projection); aux components 14-16 = radial unit vector; no params. */
+#define PCL_SRC_SPHERE_CORIOLIS 2
 int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int nparams);
 
 /* ---- SharpClaw (kind = PCL_KIND_SHARPCLAW) ----------------------------------------------------- */

@@ -1458,6 +1458,15 @@ int orc_rp1_ptr(int rp, const double *par, int meqn, int mwaves, int mbc, int mx
     return -1;
 }
 
+/* qcor.f through the C ABI (tests): aux1d(16, maxm+2mbc), q1d(meqn, maxm+2mbc), Fortran cell index i; qc4[4] */
+void orc_sphere_qcor(int ixy, int i, const double *aux1d, const double *q1d, int meqn, int mbc, const double *par,
+                     double *qc4)
+{
+    double qc[5];
+    sphere_qcor(ixy, i, aux1d, 16, q1d, meqn, mbc, par, qc);
+    for (int m = 0; m < 4; m++) qc4[m] = qc[m + 1];
+}
+
 int orc_rpt2(int rp, const double *par, int ixy, int meqn, int mbc, int mx,
              const double *q1d, const double *asdq, double *bmasdq, double *bpasdq)
 {

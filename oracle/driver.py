@@ -99,6 +99,9 @@ class Problem:
         self.user_bc_upper = None
         self.aux_bc_lower = None
         self.aux_bc_upper = None
+        self.user_aux_bc_lower = None      # f(idim, t, auxbc, mbc), solver.py:526-596
+        self.user_aux_bc_upper = None
+        self.qcor = False                  # app-local step2qcor.f in place of step2.f (shallow water on the sphere)
         self.solver_type = 'classic'
         self.lim_type = 2
         self.time_integrator = 'SSP104'
@@ -138,7 +141,8 @@ def setup(p):
         p.auxbc = np.empty((maux,) + tuple(n + 2 * p.mbc for n in ng), order="F")
         inner = (slice(None),) + (slice(p.mbc, -p.mbc),) * p.ndim
         p.auxbc[inner] = p.aux
-        fill_ghosts(p.auxbc, p.mbc, p.aux_bc_lower, p.aux_bc_upper, is_aux=True)
+        fill_ghosts(p.auxbc, p.mbc, p.aux_bc_lower, p.aux_bc_upper, p.user_aux_bc_lower, p.user_aux_bc_upper,
+                    is_aux=True)
     else:
         p.auxbc = None
 
@@ -178,8 +182,14 @@ def step_hyperbolic(p, backend):
                                        dx, dy, p.dt, p.method, p.mthlim, 2, fwave=p.fwave)
             cfl = max(cfl_x, cfl_y)
         else:
-            _, cfl = backend.step2(p.rp, p.rp_params, maxm, mbc, mx, my, qold, qnew, p.auxbc,
-                                   dx, dy, p.dt, p.method, p.mthlim, fwave=p.fwave)
+            if p.qcor:
+                backend.set_qcor(True)
+            try:
+                _, cfl = backend.step2(p.rp, p.rp_params, maxm, mbc, mx, my, qold, qnew, p.auxbc,
+                                       dx, dy, p.dt, p.method, p.mthlim, fwave=p.fwave)
+            finally:
+                if p.qcor:
+                    backend.set_qcor(False)
     p.cfl = cfl
     p.q = p.qbc[inner]                                      # set_q_from_qbc: a VIEW
 
@@ -476,3 +486,46 @@ def acoustics3d_problem(test='hom', mx=None, my=None, mz=None, **kw):
                    bc_lower=bc_lower, bc_upper=[PERIODIC] * 3, aux_bc_lower=list(bc_lower),
                    aux_bc_upper=[PERIODIC] * 3, d=tuple(2.0 / k for k in n), dim_split=dim_split,
                    order_trans=22, **kw)
+
+
+def shallow_sphere_problem(setup_backend, mx=40, my=20, Rsphere=1.0):
+    """test/shallow_sphere/shallow_4_Rossby_Haurwitz_wave.py:343-484: 4-Rossby-Haurwitz wave on the sphere, classic
+    unsplit (step2qcor) with order_trans=2, MC limiter, capa = aux[0], Strang splitting of the Coriolis source.
+    `setup_backend` supplies setaux / qinit / src2 (the C restatement, or the reference's own problem.so)."""
+    from oracle.oracle import RP_SHALLOW_SPHERE_2D
+    mbc = 2
+    xlower, xupper, ylower, yupper = -3.0, 1.0, -1.0, 1.0
+    dx, dy = (xupper - xlower) / float(mx), (yupper - ylower) / float(my)
+    auxtmp = setup_backend.sphere_setaux(mbc, mx, my, xlower, ylower, dx, dy, Rsphere)     # with ghost cells
+    qtmp = setup_backend.sphere_qinit(mbc, mx, my, xlower, ylower, dx, dy, Rsphere)
+    aux = np.array(auxtmp[:, mbc:-mbc, mbc:-mbc], order="F")
+    q = np.array(qtmp[:, mbc:-mbc, mbc:-mbc], order="F")
+
+    def qbc_lower_y(idim, t, qbc, g):           # :295-303: the ghost rows mirror the first rows, reversed in x
+        for j in range(g):
+            qbc1D = np.copy(qbc[:, :, 2 * g - 1 - j])
+            qbc[:, :, j] = qbc1D[:, ::-1]
+
+    def qbc_upper_y(idim, t, qbc, g):           # :305-313
+        for j in range(g):
+            qbc1D = np.copy(qbc[:, :, my + g - 1 - j])
+            qbc[:, :, my + g + j] = qbc1D[:, ::-1]
+
+    def auxbc_lower_y(idim, t, auxbc, g):       # :316-335: setaux evaluated on the ghost rows
+        auxbc[:, :, :g] = auxtmp[:, :, :g]
+
+    def auxbc_upper_y(idim, t, auxbc, g):       # :337-356
+        auxbc[:, :, -g:] = auxtmp[:, :, -g:]
+
+    def src(p, qv, auxv, dt):                   # fortran_src_wrapper :24-49 -> src2.f (interior arrays)
+        qf = np.array(qv, order="F")
+        setup_backend.sphere_src2(qf, np.asfortranarray(auxv), xlower, ylower, dx, dy, dt, Rsphere)
+        qv[...] = qf
+
+    return Problem(
+        q=q, aux=aux, d=(dx, dy), rp=RP_SHALLOW_SPHERE_2D, rp_params=[11489.57219, dx, dy], mwaves=3, limiters=4,
+        dim_split=False, order_trans=2, src_split=2, step_src=src, mcapa=0, qcor=True,
+        bc_lower=[PERIODIC, CUSTOM], bc_upper=[PERIODIC, CUSTOM],
+        user_bc_lower=qbc_lower_y, user_bc_upper=qbc_upper_y,
+        aux_bc_lower=[PERIODIC, CUSTOM], aux_bc_upper=[PERIODIC, CUSTOM],
+        user_aux_bc_lower=auxbc_lower_y, user_aux_bc_upper=auxbc_upper_y)

@@ -33,6 +33,7 @@ RP_SHALLOW_2D = 13
 RP_VC_ACOUSTICS_2D = 14
 RP_VC_ADVECTION_2D = 15
 RP_EULER5_2D = 11
+RP_SHALLOW_SPHERE_2D = 16
 RP_VC_ACOUSTICS_3D = 20
 
 _dp = C.POINTER(C.c_double)
@@ -89,6 +90,19 @@ class COracle:
                                       C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp]
         L.orc_weno5.restype = None
         L.orc_weno5.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.orc_sphere_qcor.restype = None
+        L.orc_sphere_qcor.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp]
+        L.orc_set_qcor.restype = None
+        L.orc_set_qcor.argtypes = [C.c_int]
+        L.orc_sphere_mapc2p.restype = None
+        L.orc_sphere_mapc2p.argtypes = [C.c_double, C.c_double, _dp, _dp, _dp, C.c_double]
+        L.orc_sphere_setaux.restype = C.c_int
+        L.orc_sphere_setaux.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_double] * 4 + [_dp, C.c_double]
+        L.orc_sphere_qinit.restype = C.c_int
+        L.orc_sphere_qinit.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_double] * 4 + [_dp, C.c_double]
+        L.orc_sphere_src2.restype = C.c_int
+        L.orc_sphere_src2.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_double] * 4 + [_dp, C.c_int, _dp, C.c_double,
+                                                                                      C.c_double]
 
     # -- f2py-shaped entry points -------------------------------------------------
     def step2ds(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim, ids,
@@ -190,6 +204,35 @@ class COracle:
         qr = np.zeros((meqn, n), order="F")
         self.lib.orc_weno5(variant, meqn, n, mbc, _d(_f64(q)), _d(ql), _d(qr))
         return ql, qr
+
+    # -- shallow water on the sphere: the app's own Fortran restated (sphere_oracle.c) -----------
+    def set_qcor(self, on):
+        """step2qcor.f in place of step2.f (test/shallow_sphere/Makefile:16)"""
+        self.lib.orc_set_qcor(int(bool(on)))
+
+    def qcor(self, ixy, i, aux1d, q1d, mbc, g, dx, dy):
+        qc = np.zeros(4)
+        par = np.array([g, dx, dy])
+        self.lib.orc_sphere_qcor(ixy, i, _d(_f64(aux1d)), _d(_f64(q1d)), q1d.shape[0], mbc, _d(par), _d(qc))
+        return qc
+
+    def sphere_setaux(self, mbc, mx, my, xlower, ylower, dx, dy, Rsphere=1.0):
+        aux = np.zeros((16, mx + 2 * mbc, my + 2 * mbc), order="F")
+        assert self.lib.orc_sphere_setaux(mbc, mx, my, xlower, ylower, dx, dy, _d(aux), Rsphere) == 0
+        return aux
+
+    def sphere_qinit(self, mbc, mx, my, xlower, ylower, dx, dy, Rsphere=1.0):
+        q = np.zeros((4, mx + 2 * mbc, my + 2 * mbc), order="F")
+        assert self.lib.orc_sphere_qinit(mbc, mx, my, xlower, ylower, dx, dy, _d(q), Rsphere) == 0
+        return q
+
+    def sphere_src2(self, q, aux, xlower, ylower, dx, dy, dt, Rsphere=1.0):
+        """problem.src2(mx,my,mbc,xlower,ylower,dx,dy,q,aux,t,dt,Rsphere) on the interior arrays; q in place"""
+        assert q.flags.f_contiguous and aux.flags.f_contiguous
+        meqn, mx, my = q.shape
+        assert self.lib.orc_sphere_src2(meqn, mx, my, xlower, ylower, dx, dy, _d(q), aux.shape[0], _d(aux), dt,
+                                        Rsphere) == 0
+        return q
 
     # -- slice-level pieces -------------------------------------------------------
     def rpn2(self, rp, par, ixy, mwaves, mbc, mx, q1d):
@@ -332,3 +375,59 @@ class RefSharp2DEuler:
         self.lib.flux2_(_d(q), _d(dq), _d(q1d), _d(dq1d), _d(auxd), C.byref(C.c_double(dt)), C.byref(cfl),
                         C.byref(C.c_double(0.0)), ci(0), ci(meqn), ci(mbc), ci(max(mx, my)), ci(mx), ci(my))
         return dq, cfl.value
+
+
+class RefSphereProblem:
+    """The shallow-sphere application's own Fortran (test/shallow_sphere/{mapc2p,setaux,qinit,src2,qcor}.f), flang-built
+    by oracle/Makefile into oracle/_ref/libref_sphere_problem.so: what the reference's Makefile calls problem.so.
+    By-reference arguments in the order of the Fortran statements (setaux.f:2-3, qinit.f:2-3, src2.f:2-3)."""
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "_ref", "libref_sphere_problem.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "libref_sphere_problem.so"))
+
+    def sphere_setaux(self, mbc, mx, my, xlower, ylower, dx, dy, Rsphere=1.0):
+        aux = np.zeros((16, mx + 2 * mbc, my + 2 * mbc), order="F")
+        ci = lambda v: C.byref(C.c_int(v))
+        cd = lambda v: C.byref(C.c_double(v))
+        self.lib.setaux_(ci(mx), ci(my), ci(mbc), ci(mx), ci(my), cd(xlower), cd(ylower), cd(dx), cd(dy), ci(16),
+                         _d(aux), cd(Rsphere))
+        return aux
+
+    def sphere_qinit(self, mbc, mx, my, xlower, ylower, dx, dy, Rsphere=1.0):
+        q = np.zeros((4, mx + 2 * mbc, my + 2 * mbc), order="F")
+        aux = np.zeros((16, mx + 2 * mbc, my + 2 * mbc), order="F")
+        ci = lambda v: C.byref(C.c_int(v))
+        cd = lambda v: C.byref(C.c_double(v))
+        self.lib.qinit_(ci(mx), ci(my), ci(4), ci(mbc), ci(mx), ci(my), cd(xlower), cd(ylower), cd(dx), cd(dy), _d(q),
+                        ci(16), _d(aux), cd(Rsphere))
+        return q
+
+    def sphere_src2(self, q, aux, xlower, ylower, dx, dy, dt, Rsphere=1.0):
+        assert q.flags.f_contiguous and aux.flags.f_contiguous
+        meqn, mx, my = q.shape
+        ci = lambda v: C.byref(C.c_int(v))
+        cd = lambda v: C.byref(C.c_double(v))
+        self.lib.src2_(ci(mx), ci(my), ci(meqn), ci(2), ci(mx), ci(my), cd(xlower), cd(ylower), cd(dx), cd(dy), _d(q),
+                       ci(aux.shape[0]), _d(aux), cd(0.0), cd(dt), cd(Rsphere))
+        return q
+
+    def qcor(self, ixy, i, aux1d, q1d, mbc, g, dx, dy):
+        """qcor(ixy,i,m,aux,q,maxm,meqn,mbc,qc): aux1d (16, maxm+2mbc), q1d (meqn, maxm+2mbc); i is the Fortran index"""
+        class _Comxyt(C.Structure):
+            _fields_ = [("dtcom", C.c_double), ("dxcom", C.c_double), ("dycom", C.c_double), ("tcom", C.c_double),
+                        ("icom", C.c_int), ("jcom", C.c_int)]
+        _Comxyt.in_dll(self.lib, "comxyt_").dxcom = dx
+        _Comxyt.in_dll(self.lib, "comxyt_").dycom = dy
+        C.c_double.in_dll(self.lib, "sw_").value = g
+        meqn, n = q1d.shape
+        qc = np.zeros(4)
+        ci = lambda v: C.byref(C.c_int(v))
+        self.lib.qcor_(ci(ixy), ci(i), ci(0), _d(_f64(aux1d)), _d(_f64(q1d)), ci(n - 2 * mbc), ci(meqn), ci(mbc), _d(qc))
+        return qc

@@ -182,6 +182,7 @@ int orc_sphere_src2(int meqn, int mx, int my, double xlower, double ylower, doub
 {
     const double df = (double)12.600576f;     /* src2.f:39: df=12.600576e0, a REAL*4 literal */
 #define Q(m, i, j) q[((m)-1) + (size_t)meqn * (((i)-1) + (size_t)mx * ((j)-1))]
+#undef AUX
 #define AUX(ma, i, j) aux[((ma)-1) + (size_t)maux * (((i)-1) + (size_t)mx * ((j)-1))]
     for (int pass = 0; pass < 2; pass++) {
         for (int i = 1; i <= mx; i++)

@@ -8,13 +8,13 @@ there is no CPU fallback.
 """
 from . import limiters, riemann
 from .cfl import CFL
-from .clawpack import ClawSolver1D, ClawSolver2D, ClawSolver3D, DeviceSource, EulerRadialSource
+from .clawpack import ClawSolver1D, ClawSolver2D, ClawSolver3D, DeviceSource, EulerRadialSource, SphereCoriolisSource
 from .controller import Controller
 from .grid import Dimension, Grid
 from .sharpclaw import SharpClawSolver1D, SharpClawSolver2D
 from .solution import Solution
-from .solver import BC, ConstantStateBC, DeviceBC
+from .solver import BC, ConstantStateBC, DeviceBC, SphereMirrorBC
 from .state import State
 
-__all__ = ['limiters', 'riemann', 'CFL', 'ClawSolver1D', 'ClawSolver2D', 'ClawSolver3D', 'DeviceSource', 'EulerRadialSource',
+__all__ = ['limiters', 'riemann', 'CFL', 'ClawSolver1D', 'ClawSolver2D', 'ClawSolver3D', 'DeviceSource', 'EulerRadialSource', 'SphereCoriolisSource', 'SphereMirrorBC',
            'Controller', 'SharpClawSolver1D', 'SharpClawSolver2D', 'Dimension', 'Grid', 'Solution', 'BC', 'ConstantStateBC', 'DeviceBC', 'State']

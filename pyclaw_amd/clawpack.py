@@ -37,6 +37,15 @@ class EulerRadialSource(DeviceSource):
         _lib.check(_lib.lib().pcl_src(solver._h, 1, dt, _lib.d(self.params), 2))
 
 
+class SphereCoriolisSource(DeviceSource):
+    """Coriolis source of the shallow-water-on-the-sphere app (apps/shallow-sphere/src2.f, wrapped by
+    ``fortran_src_wrapper``, shallow_4_Rossby_Haurwitz_wave.py:24-49): projection onto the tangent plane, 4-stage RK,
+    projection.  aux[13:16] must hold the radial unit vector (setaux.f:150-156)."""
+
+    def apply(self, solver, state, dt):
+        _lib.check(_lib.lib().pcl_src(solver._h, 2, dt, None, 0))
+
+
 class ClawSolver(Solver):
     r"""Generic classic Clawpack solver (clawpack.py:24-262)."""
 
@@ -182,7 +191,7 @@ class ClawSolver(Solver):
             raise Exception("solver.mwaves=%d but Riemann solver %s has %d waves" % (self.mwaves, rp.name, rp.mwaves))
         if rp.meqn != state.meqn:
             raise Exception("state.meqn=%d but Riemann solver %s has %d equations" % (state.meqn, rp.name, rp.meqn))
-        params = rp.params(state.aux_global)          # the cparam common block (state.py:142-162)
+        params = rp.all_params(state)                 # the cparam common block (state.py:142-162)
 
         self._release()
         cfg = _lib.Config()

@@ -17,6 +17,7 @@
 // column strips out) so both passes run the same lane-per-cell core.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "rp.hpp"
 
 namespace pcl {
@@ -50,6 +51,26 @@ template <class T> __device__ __forceinline__ T struct_from_left(const T &t) {
     for (int k = 0; k < N; k++) b.d[k] = from_left(a.d[k]);
     return b.t;
 }
+
+// ---- which aux components a Riemann solver reads ---------------------------------------------------
+// Solvers with cell-wise coefficients name the aux planes they need (rp.hpp): aux_index<IXY>(k), k < NAUX, for
+// the sweep itself (staged next to q in the LDS tiles) and auxt_index<IXY>(k), k < NAUX_T, for the transverse
+// solves (read for the cell and its two neighbours across the sweep).  Solvers without aux have neither.
+template <class RP, int IXY> __host__ __device__ constexpr int aux_idx(int k) {
+    if constexpr (RP::NAUX > 0) return RP::template aux_index<IXY>(k);
+    else return k;
+}
+template <class RP, int IXY> __host__ __device__ constexpr int auxt_idx(int k) {
+    if constexpr (RP::NAUX > 0) return RP::template auxt_index<IXY>(k);
+    else return k;
+}
+template <class RP> __host__ __device__ constexpr int naux_t() {
+    if constexpr (RP::NAUX > 0) return RP::NAUX_T;
+    else return 0;
+}
+template <class RP, class = void> struct HasQcor : std::false_type {};
+template <class RP> struct HasQcor<RP, std::void_t<decltype(RP::HAS_QCOR)>> : std::bool_constant<RP::HAS_QCOR> {};
+template <class RP> __host__ __device__ constexpr bool has_qcor() { return HasQcor<RP>::value; }
 
 // philim.f:19-55
 __device__ __forceinline__ double philim(double a, double b, int meth) {
@@ -122,7 +143,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                                           double (&qn)[RP::MEQN], double &cflmax,
                                           double *df = nullptr, double *g1 = nullptr, double *g2 = nullptr,
                                           const double *auxv = nullptr, const double *auxb = nullptr,
-                                          const double *auxa = nullptr) {
+                                          const double *auxa = nullptr, const double *auxo = nullptr) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     using Cell = typename RP::Cell;
 
@@ -259,15 +280,19 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                 for (int m = 0; m < MEQN; m++) { amdq[m] = amdq[m] + cq[m]; apdq[m] = apdq[m] - cq[m]; }
             }
             double bm[MEQN], bp[MEQN];
-            // solvers with cell-wise coefficients: aux of the cells below / above in the neighbouring slices --
-            // of this lane's cell for A^+ dq, of the left neighbour's (shifted) for A^- dq
-            double auxbl[RP::NAUX > 0 ? RP::NAUX : 1], auxal[RP::NAUX > 0 ? RP::NAUX : 1];
+            // solvers with cell-wise coefficients: transverse aux set of the cell itself and of the cells below /
+            // above in the neighbouring slices -- of this lane's cell for A^+ dq, of the left neighbour's
+            // (shifted) for A^- dq
+            constexpr int NT = naux_t<RP>() > 0 ? naux_t<RP>() : 1;
+            double auxol[NT], auxbl[NT], auxal[NT];
             if constexpr (RP::NAUX > 0) {
 #pragma unroll
-                for (int k = 0; k < RP::NAUX; k++) { auxbl[k] = from_left(auxb[k]); auxal[k] = from_left(auxa[k]); }
+                for (int k = 0; k < NT; k++) {
+                    auxol[k] = from_left(auxo[k]); auxbl[k] = from_left(auxb[k]); auxal[k] = from_left(auxa[k]);
+                }
             }
             // B^-/B^+ A^- dq of interface l modify the cell to its LEFT (flux2.f:167-176)
-            if constexpr (RP::NAUX > 0) RP::template transverse_vc<IXY>(cL, auxbl, auxal, amdq, bm, bp);
+            if constexpr (RP::NAUX > 0) RP::template transverse_vc<IXY>(cL, auxol, auxbl, auxal, a.par, amdq, bm, bp);
             else RP::template transverse<IXY>(cL, cR, a.par, amdq, bm, bp);
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
@@ -275,7 +300,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                 g2[m] = -(0.5 * dtdx_c * from_right(bp[m]));
             }
             // B^-/B^+ A^+ dq of interface l modify this cell (flux2.f:180-189)
-            if constexpr (RP::NAUX > 0) RP::template transverse_vc<IXY>(cR, auxb, auxa, apdq, bm, bp);
+            if constexpr (RP::NAUX > 0) RP::template transverse_vc<IXY>(cR, auxo, auxb, auxa, a.par, apdq, bm, bp);
             else RP::template transverse<IXY>(cL, cR, a.par, apdq, bm, bp);
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
@@ -444,7 +469,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
                     for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = a.qin[m * a.plane + g];
                     if constexpr (CAPA) tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
 #pragma unroll
-                    for (int m = 0; m < NAUX; m++) tile[T::at(PAUX + m, al, ac)] = a.aux[m * a.plane + g];
+                    for (int m = 0; m < NAUX; m++) tile[T::at(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + g];
                 }
             } else {
                 // qbc = Y(X(q)): x sides first, then y sides over the x-filled array (solver.py:354-381)
@@ -472,7 +497,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
                         tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + (long)gb * a.pitch + ga];
 #pragma unroll
                     for (int m = 0; m < NAUX; m++)   // aux ghost cells are real memory (auxbc is filled once at setup)
-                        tile[T::at(PAUX + m, al, ac)] = a.aux[m * a.plane + (long)gb * a.pitch + ga];
+                        tile[T::at(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + (long)gb * a.pitch + ga];
                 }
             }
         }
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = a.qin[m * a.plane + g];
             if constexpr (CAPA) tile[T::at(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
 #pragma unroll
-            for (int m = 0; m < NAUX; m++) tile[T::at(PAUX + m, al, ac)] = a.aux[m * a.plane + g];
+            for (int m = 0; m < NAUX; m++) tile[T::at(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + g];
         }
     }
     __syncthreads();
@@ -546,20 +571,39 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             // unsplit algorithm: this slice's pieces for the cell go to scratch planes; they are
             // summed into qnew in the reference's order by combine_kernel (step2.f:130-137,214-218)
             double df[MEQN], g1[MEQN], g2[MEQN];
-            // transverse solvers with cell-wise coefficients: aux of the cells in the slices below / above
-            double auxb[NAUX > 0 ? NAUX : 1], auxa[NAUX > 0 ? NAUX : 1];
+            // transverse solvers with cell-wise coefficients: their aux set of the cell itself and of the cells in
+            // the slices below / above
+            constexpr int NT = naux_t<RP>() > 0 ? naux_t<RP>() : 1;
+            double auxo[NT], auxb[NT], auxa[NT];
             if constexpr (NAUX > 0) {
                 const int gbc = b0 + ac < n_across ? b0 + ac : n_across - 1;
                 const int gbb = gbc > 0 ? gbc - 1 : 0, gba = gbc + 1 < n_across ? gbc + 1 : n_across - 1;
                 const int cac = ca < n_along ? ca : n_along - 1;
 #pragma unroll
-                for (int m = 0; m < NAUX; m++) {
-                    auxb[m] = a.aux[m * a.plane + (IXY == 1 ? (long)gbb * a.pitch + cac : (long)cac * a.pitch + gbb)];
-                    auxa[m] = a.aux[m * a.plane + (IXY == 1 ? (long)gba * a.pitch + cac : (long)cac * a.pitch + gba)];
+                for (int m = 0; m < NT; m++) {
+                    const long pl = auxt_idx<RP, IXY>(m) * a.plane;
+                    auxo[m] = a.aux[pl + (IXY == 1 ? (long)gbc * a.pitch + cac : (long)cac * a.pitch + gbc)];
+                    auxb[m] = a.aux[pl + (IXY == 1 ? (long)gbb * a.pitch + cac : (long)cac * a.pitch + gbb)];
+                    auxa[m] = a.aux[pl + (IXY == 1 ? (long)gba * a.pitch + cac : (long)cac * a.pitch + gba)];
                 }
             }
             lane_core<RP, IXY, CAPA, FWAVE, DIM1, true>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, df, g1, g2, auxv, auxb,
-                                                        auxa);
+                                                        auxa, auxo);
+            // conservation fix on the sphere (step2qcor.f:146-159,232-245 + qcor.f): the cell's own edge and the
+            // next cell's edge along the sweep, both still in the LDS tile
+            double qc[MEQN];
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) qc[m] = 0.0;
+            if constexpr (has_qcor<RP>() && CAPA) {
+                double er_[6];
+                const int aln = al + 1 < T::ALONG ? al + 1 : al;
+#pragma unroll
+                for (int k = 0; k < 6; k++) er_[k] = tile[T::at(PAUX + k, aln, ac)];
+                double qc4[4];
+                RP::template qcor<IXY>(q, auxv, er_, auxv + 6, a.par, qc4);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) qc[m] = qc4[m];
+            }
             if (owned) {
                 const int gb = b0 + ac;
                 const long g = IXY == 1 ? (long)gb * a.pitch + ca : (long)ca * a.pitch + gb;
@@ -580,6 +624,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
                     }
                     a.scr[3][at] = a.dtd_t * g1[m];
                     a.scr[4][at] = a.dtd_t * g2[m];
+                    if constexpr (has_qcor<RP>() && CAPA) a.scr[5][at] = a.dtd * qc[m];
                 }
             }
         } else {
@@ -665,17 +710,22 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, i
     const bool cfl_ok = slice_ok && (ca >= a.mbc) && (ca <= a.mbc + a.mx) && lane >= 1;
     // solver aux of this row and of the rows below / above it (step2.f:97-101: aux1, aux2, aux3)
     constexpr int NAUX = RP::NAUX;
-    double auxv[NAUX > 0 ? NAUX : 1], auxb[NAUX > 0 ? NAUX : 1], auxa[NAUX > 0 ? NAUX : 1];
+    constexpr int NT = naux_t<RP>() > 0 ? naux_t<RP>() : 1;
+    double auxv[NAUX > 0 ? NAUX : 1], auxo[NT], auxb[NT], auxa[NT];
     if constexpr (NAUX > 0) {
         const int rb = rc > 0 ? rc - 1 : 0, ra = rc + 1 < a.J ? rc + 1 : a.J - 1;
 #pragma unroll
-        for (int m = 0; m < NAUX; m++) {
-            auxv[m] = a.aux[m * a.plane + g];
-            auxb[m] = a.aux[m * a.plane + (long)rb * a.pitch + cc];
-            auxa[m] = a.aux[m * a.plane + (long)ra * a.pitch + cc];
+        for (int m = 0; m < NAUX; m++) auxv[m] = a.aux[aux_idx<RP, 1>(m) * a.plane + g];
+#pragma unroll
+        for (int m = 0; m < NT; m++) {
+            const long pl = auxt_idx<RP, 1>(m) * a.plane;
+            auxo[m] = a.aux[pl + g];
+            auxb[m] = a.aux[pl + (long)rb * a.pitch + cc];
+            auxa[m] = a.aux[pl + (long)ra * a.pitch + cc];
         }
     }
-    lane_core<RP, 1, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa);
+    lane_core<RP, 1, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa,
+                                                auxo);
 #pragma unroll
     for (int m = 0; m < MEQN; m++) {
         gm[w][m][lane] = a.dtd_t * g1[m];
@@ -730,19 +780,24 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
     const bool cfl_ok = slice_ok && (cj >= a.mbc) && (cj <= a.mbc + a.my) && lane >= 1;
     // solver aux of this column and of the columns to its left / right (step2.f:177-181)
     constexpr int NAUX = RP::NAUX;
-    double auxv[NAUX > 0 ? NAUX : 1], auxb[NAUX > 0 ? NAUX : 1], auxa[NAUX > 0 ? NAUX : 1];
+    constexpr int NT = naux_t<RP>() > 0 ? naux_t<RP>() : 1;
+    double auxv[NAUX > 0 ? NAUX : 1], auxo[NT], auxb[NT], auxa[NT];
     if constexpr (NAUX > 0) {
         const int gj = cj < a.J ? cj : a.J - 1;
         const int c0 = col < a.I ? col : a.I - 1;
         const int cb = c0 > 0 ? c0 - 1 : 0, cn = c0 + 1 < a.I ? c0 + 1 : a.I - 1;
 #pragma unroll
-        for (int m = 0; m < NAUX; m++) {
-            auxv[m] = a.aux[m * a.plane + (long)gj * a.pitch + c0];
-            auxb[m] = a.aux[m * a.plane + (long)gj * a.pitch + cb];
-            auxa[m] = a.aux[m * a.plane + (long)gj * a.pitch + cn];
+        for (int m = 0; m < NAUX; m++) auxv[m] = a.aux[aux_idx<RP, 2>(m) * a.plane + (long)gj * a.pitch + c0];
+#pragma unroll
+        for (int m = 0; m < NT; m++) {
+            const long pl = auxt_idx<RP, 2>(m) * a.plane;
+            auxo[m] = a.aux[pl + (long)gj * a.pitch + c0];
+            auxb[m] = a.aux[pl + (long)gj * a.pitch + cb];
+            auxa[m] = a.aux[pl + (long)gj * a.pitch + cn];
         }
     }
-    lane_core<RP, 2, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa);
+    lane_core<RP, 2, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa,
+                                                auxo);
 #pragma unroll
     for (int m = 0; m < MEQN; m++) {
         gm[w][m][lane] = a.dtd_t * g1[m];
@@ -777,7 +832,7 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
 //   q3 = q2 - dtdy*gadd1 [slice j+1]            q6 = q5 - dtdx*gadd1 [slice i+1]
 // (with a capacity function every increment is divided by capa of the TARGET cell and the two
 // flux-difference terms are summed first, step2.f:145-152,227-234).  One thread per cell.
-template <bool CAPA>
+template <bool CAPA, bool QCOR = false>
 __global__ __launch_bounds__(256) void combine_kernel(CombineArgs c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
@@ -795,9 +850,11 @@ __global__ __launch_bounds__(256) void combine_kernel(CombineArgs c) {
         if (CAPA) {
             q = q + c.x[4][at - c.pitch] / capa;
             q = q + c.x[0][at] - c.x[1][at] / capa;
+            if (QCOR) q = q - c.x[5][at] / capa;          // step2qcor.f:157: right after the cell's own x update
             q = q - c.x[3][at + c.pitch] / capa;
             q = q + c.y[3][at - 1] / capa;
             q = q + c.y[0][at] - c.y[1][at] / capa;
+            if (QCOR) q = q - c.y[4][at] / capa;          // step2qcor.f:243
             q = q - c.y[2][at + 1] / capa;
         } else {
             q = q + c.x[4][at - c.pitch];
@@ -850,7 +907,7 @@ __global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac,
 #pragma unroll
         for (int m = 0; m < MEQN; m++) tile[at(m, al, ac)] = a.qin[m * a.plane + g];
 #pragma unroll
-        for (int m = 0; m < NAUX; m++) tile[at(MEQN + m, al, ac)] = a.aux[m * a.plane + g];
+        for (int m = 0; m < NAUX; m++) tile[at(MEQN + m, al, ac)] = a.aux[aux_idx<RP, DIR>(m) * a.plane + g];
     };
     if (DIR == 1) {
         if ((int)threadIdx.x < ALONG) {

@@ -74,6 +74,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 1, false>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 1, false>(l, err);
         if (rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 1, false>(l, err);
+        if (rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 1, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false>(l, err);
@@ -81,6 +82,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 2, false>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 2, false>(l, err);
         if (rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 2, false>(l, err);
+        if (rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 2, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -131,6 +133,7 @@ int launch_slices(const SweepLaunch &l, std::string &err) {
         if (l.rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 1, false, true>(l, err);
+        if (l.rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 1, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false, true>(l, err);
     } else {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false, true>(l, err);
@@ -138,6 +141,7 @@ int launch_slices(const SweepLaunch &l, std::string &err) {
         if (l.rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 2, false, true>(l, err);
+        if (l.rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 2, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false, true>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -187,7 +191,9 @@ int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
 
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err) {
     const dim3 grid((unsigned)((c.I + 255) / 256), (unsigned)c.J);
-    if (c.mcapa > 0)
+    if (c.mcapa > 0 && c.qcor)
+        hipLaunchKernelGGL((combine_kernel<true, true>), grid, dim3(256), 0, stream, c);
+    else if (c.mcapa > 0)
         hipLaunchKernelGGL(combine_kernel<true>, grid, dim3(256), 0, stream, c);
     else
         hipLaunchKernelGGL(combine_kernel<false>, grid, dim3(256), 0, stream, c);
@@ -232,6 +238,7 @@ int launch_sharp(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_SHALLOW_2D) return launch_sharp_t<Shallow2D, 1>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch_sharp_t<VcAcoustics2D, 1>(l, err);
         if (rp == PCL_RP_VC_ADVECTION_2D) return launch_sharp_t<VcAdvection2D, 1>(l, err);
+        if (rp == PCL_RP_SHALLOW_SPHERE_2D) return launch_sharp_t<ShallowSphere, 1>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 1>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 2>(l, err);
@@ -239,6 +246,7 @@ int launch_sharp(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_SHALLOW_2D) return launch_sharp_t<Shallow2D, 2>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch_sharp_t<VcAcoustics2D, 2>(l, err);
         if (rp == PCL_RP_VC_ADVECTION_2D) return launch_sharp_t<VcAdvection2D, 2>(l, err);
+        if (rp == PCL_RP_SHALLOW_SPHERE_2D) return launch_sharp_t<ShallowSphere, 2>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 2>(l, err);
     }
     err = "Riemann solver id does not match the grid dimension";

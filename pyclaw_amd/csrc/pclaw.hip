@@ -43,7 +43,7 @@ struct pcl_solver {
     double *aux = nullptr;
     double *sreg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // SharpClaw registers (0 aliases q)
     int sel = 0;          // register the put/get/bc/strip/halo calls act on
-    double *scr[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // unsplit slice pieces
+    double *scr[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // unsplit slice pieces ([9], [10]: qcor of the x / y slices)
     double *stage = nullptr;  // AoS staging for host transfers (qbc-sized)
     size_t stage_bytes = 0;
     unsigned long long *cfl_dev = nullptr;
@@ -197,6 +197,52 @@ __global__ void src_euler_radial(double *q, const double *aux, int mbc, int mx, 
     q[plane + g] = q1 - k1 * rho * u * v;
     q[2 * plane + g] = q2 - k1 * rho * v * v;
     q[3 * plane + g] = q3 - k1 * v * (s3 + press);
+}
+
+// ---- sphere app: custom y boundary, shallow_4_Rossby_Haurwitz_wave.py:295-313 ---------------------------
+// lower: qbc[:, i, j] = qbc[:, I-1-i, 2*mbc-1-j]; upper: qbc[:, i, J-mbc+j] = qbc[:, I-1-i, J-mbc-1-j]   (j < mbc, all i)
+__global__ void bc_sphere_mirror(double *q, int nm, int I, int J, long pitch, long plane, int mbc, int side) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)I * mbc;
+    if (tid >= per * nm) return;
+    const int m = (int)(tid / per), rem = (int)(tid % per), j = rem / I, i = rem % I;
+    const int dst = side == 0 ? j : J - mbc + j;
+    const int src = side == 0 ? 2 * mbc - 1 - j : J - mbc - 1 - j;
+    q[m * plane + (long)dst * pitch + i] = q[m * plane + (long)src * pitch + (I - 1 - i)];
+}
+
+// ---- sphere app: Coriolis source, apps/shallow-sphere/src2.f:43-146 -----------------------------------------
+// Per interior cell: project the momentum onto the tangent plane, 4-stage Runge-Kutta on the Coriolis term,
+// project again.  src2.f takes the radial vector of the Coriolis part from mapc2p(cell centre): the very values
+// setaux.f:150-156 stored in aux(14:16) (same expression, same arguments).  The Fortran does the three phases in
+// three loops over the grid; cells are independent, so one pass per cell gives the same numbers.
+__global__ void src_sphere_coriolis(double *q, const double *aux, int mbc, int mx, int my, long pitch, long plane,
+                                    double dt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= mx || j >= my) return;
+    const long g = (long)(j + mbc) * pitch + (i + mbc);
+    const double df = (double)12.600576f;            // src2.f:39: a REAL*4 literal
+    const double erx = aux[13 * plane + g], ery = aux[14 * plane + g], erz = aux[15 * plane + g];
+    double q2 = q[plane + g], q3 = q[2 * plane + g], q4 = q[3 * plane + g];
+    double qn = erx * q2 + ery * q3 + erz * q4;
+    q2 = q2 - qn * erx; q3 = q3 - qn * ery; q4 = q4 - qn * erz;
+    const double fcor = df * erz;
+    double hu = q2, hv = q3, hw = q4, k1[3], k2[3], k3[3], k4[3];
+    k1[0] = fcor * dt * (erz * hv - ery * hw); k1[1] = dt * fcor * (erx * hw - erz * hu); k1[2] = dt * fcor * (ery * hu - erx * hv);
+    hu = q2 + 0.5 * k1[0]; hv = q3 + 0.5 * k1[1]; hw = q4 + 0.5 * k1[2];
+    k2[0] = fcor * dt * (erz * hv - ery * hw); k2[1] = dt * fcor * (erx * hw - erz * hu); k2[2] = dt * fcor * (ery * hu - erx * hv);
+    hu = q2 + 0.5 * k2[0]; hv = q3 + 0.5 * k2[1]; hw = q4 + 0.5 * k2[2];
+    k3[0] = fcor * dt * (erz * hv - ery * hw); k3[1] = dt * fcor * (erx * hw - erz * hu); k3[2] = dt * fcor * (ery * hu - erx * hv);
+    hu = q2 + 0.5 * k3[0]; hv = q3 + 0.5 * k3[1]; hw = q4 + 0.5 * k3[2];
+    k4[0] = fcor * dt * (erz * hv - ery * hw); k4[1] = dt * fcor * (erx * hw - erz * hu); k4[2] = dt * fcor * (ery * hu - erx * hv);
+    q2 = q2 + (k1[0] + 2.0 * k2[0] + 2.0 * k3[0] + k4[0]) / 6.0;
+    q3 = q3 + (k1[1] + 2.0 * k2[1] + 2.0 * k3[1] + k4[1]) / 6.0;
+    q4 = q4 + (k1[2] + 2.0 * k2[2] + 2.0 * k3[2] + k4[2]) / 6.0;
+    qn = erx * q2 + ery * q3 + erz * q4;
+    q[plane + g] = q2 - qn * erx;
+    q[2 * plane + g] = q3 - qn * ery;
+    q[3 * plane + g] = q4 - qn * erz;
 }
 
 // ---- sweep dispatch ---------------------------------------------------------------------------
@@ -374,7 +420,8 @@ int do_unsplit_lds(pcl_solver *s, double dt) {
 int do_unsplit(pcl_solver *s, double dt) {
     if (s->cfg.method[5] == 0) return do_unsplit_lds(s, dt);
     const size_t qbytes = ((size_t)s->total + 16) * sizeof(double);
-    for (int k = 0; k < 9; k++) {
+    const bool qcor = s->cfg.rp == PCL_RP_SHALLOW_SPHERE_2D;   // the app's step2qcor.f
+    for (int k = 0; k < (qcor ? 11 : 9); k++) {
         if (s->scr[k]) continue;
         double *raw = nullptr;
         HIP_TRY(hipMalloc((void **)&raw, qbytes));
@@ -389,9 +436,11 @@ int do_unsplit(pcl_solver *s, double dt) {
         l.a.dtd_t = dt / s->cfg.d[2 - ids];
         if (ids == 1) {
             for (int k = 0; k < 5; k++) l.a.scr[k] = s->scr[k];
+            l.a.scr[5] = s->scr[9];
         } else {  // the y slices never write slot 2 (step2.f:214-216 keeps one parenthesised term)
             l.a.scr[0] = s->scr[5]; l.a.scr[1] = s->scr[6]; l.a.scr[2] = nullptr;
             l.a.scr[3] = s->scr[7]; l.a.scr[4] = s->scr[8];
+            l.a.scr[5] = s->scr[10];
         }
         l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = s->stream;
         pcl_solver::Timed t{};
@@ -404,6 +453,8 @@ int do_unsplit(pcl_solver *s, double dt) {
     c.qold = s->q; c.qnew = s->t1; c.aux = s->aux;
     for (int k = 0; k < 5; k++) c.x[k] = s->scr[k];
     c.y[0] = s->scr[5]; c.y[1] = s->scr[6]; c.y[2] = s->scr[7]; c.y[3] = s->scr[8];
+    c.x[5] = s->scr[9]; c.y[4] = s->scr[10];
+    c.qcor = qcor ? 1 : 0;
     c.pitch = s->pitch; c.plane = s->plane; c.I = s->I; c.J = s->J; c.mbc = s->cfg.mbc;
     c.mx = s->cfg.n[0]; c.my = s->cfg.n[1]; c.mcapa = s->cfg.method[5]; c.meqn = s->cfg.meqn;
     int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_combine(c, s->stream, err)
@@ -518,6 +569,7 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     case PCL_RP_SHALLOW_2D: want_meqn = 3; want_mwaves = 3; want_ndim = 2; break;
     case PCL_RP_VC_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
     case PCL_RP_VC_ADVECTION_2D: want_meqn = 1; want_mwaves = 1; want_ndim = 2; break;
+    case PCL_RP_SHALLOW_SPHERE_2D: want_meqn = 4; want_mwaves = 3; want_ndim = 2; break;
     case PCL_RP_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
     case PCL_RP_EULER5_2D: want_meqn = 5; want_mwaves = 5; want_ndim = 2; break;
     case PCL_RP_VC_ACOUSTICS_3D: want_meqn = 4; want_mwaves = 2; want_ndim = 3; break;
@@ -532,6 +584,13 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
         return fail(PCL_EINVAL, "rp1_advection_color needs aux(1) = edge velocity");
     if (cfg->rp == PCL_RP_VC_ACOUSTICS_2D || cfg->rp == PCL_RP_VC_ADVECTION_2D) {
         if (cfg->maux < 2) return fail(PCL_EINVAL, "this Riemann solver needs two aux components (impedance/sound speed or the edge velocities)");
+    }
+    if (cfg->rp == PCL_RP_SHALLOW_SPHERE_2D) {
+        if (cfg->maux < 16) return fail(PCL_EINVAL, "rpn2_shallow_sphere needs the 16 aux components of setaux.f (kappa, edge normals/tangents, radial vector)");
+        if (!(cfg->rp_params[0] > 0.0) || !(cfg->rp_params[1] > 0.0) || !(cfg->rp_params[2] > 0.0))
+            return fail(PCL_EINVAL, "rpn2_shallow_sphere: rp_params must be g, dxcom, dycom (all > 0)");
+        if (cfg->kind == PCL_KIND_CLASSIC && cfg->method[2] >= 0 && cfg->method[5] == 0)
+            return fail(PCL_EINVAL, "shallow water on the sphere, unsplit: the capacity function (mcapa) must be set (step2qcor.f)");
     }
     if (cfg->ndim == 3) {
         if (cfg->kind != PCL_KIND_CLASSIC) return fail(PCL_EINVAL, "3-D: classic solver only (the reference has no 3-D SharpClaw)");
@@ -780,9 +839,17 @@ static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *
 int pcl_bc(pcl_solver *s, int idim, int side, int bctype) {
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (idim < 0 || idim >= s->cfg.ndim || side < 0 || side > 1) return fail(PCL_EINVAL, "bad idim/side");
-    if (bctype != PCL_BC_OUTFLOW && bctype != PCL_BC_PERIODIC && bctype != PCL_BC_REFLECTING)
-        return fail(PCL_EINVAL, "pcl_bc: only outflow/periodic/reflecting run here");
     HIP_TRY(hipSetDevice(s->cfg.device));
+    if (bctype == PCL_BC_SPHERE_MIRROR) {
+        if (s->cfg.ndim != 2 || idim != 1) return fail(PCL_EINVAL, "PCL_BC_SPHERE_MIRROR is the y boundary of a 2-D grid");
+        const long n = (long)s->I * s->cfg.mbc * s->cfg.meqn;
+        hipLaunchKernelGGL(bc_sphere_mirror, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, cur(s),
+                           s->cfg.meqn, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, side);
+        HIP_TRY(hipGetLastError());
+        return PCL_OK;
+    }
+    if (bctype != PCL_BC_OUTFLOW && bctype != PCL_BC_PERIODIC && bctype != PCL_BC_REFLECTING)
+        return fail(PCL_EINVAL, "pcl_bc: only outflow/periodic/reflecting/sphere-mirror run here");
     return bc_launch(s, idim, side, bctype, nullptr);
 }
 
@@ -974,6 +1041,15 @@ int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int npar
         dim3 grid((s->cfg.n[0] + 255) / 256, s->cfg.n[1]);
         hipLaunchKernelGGL(src_euler_radial, grid, dim3(256), 0, s->stream, s->q, s->aux, s->cfg.mbc,
                            s->cfg.n[0], s->cfg.n[1], s->pitch, s->plane, dt, params[0], params[1] - 1.0);
+        HIP_TRY(hipGetLastError());
+        return PCL_OK;
+    }
+    if (src_id == PCL_SRC_SPHERE_CORIOLIS) {
+        if (s->cfg.meqn != 4 || s->cfg.maux < 16 || s->cfg.ndim != 2 || !s->aux)
+            return fail(PCL_EINVAL, "sphere Coriolis source needs q = (h,hu,hv,hw) and the 16 aux components of setaux.f");
+        dim3 grid((s->cfg.n[0] + 255) / 256, s->cfg.n[1]);
+        hipLaunchKernelGGL(src_sphere_coriolis, grid, dim3(256), 0, s->stream, cur(s), s->aux, s->cfg.mbc, s->cfg.n[0],
+                           s->cfg.n[1], s->pitch, s->plane, dt);
         HIP_TRY(hipGetLastError());
         return PCL_OK;
     }

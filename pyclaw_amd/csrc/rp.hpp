@@ -162,7 +162,9 @@ struct Advection1D {
 // velocity at its LEFT edge, so interface i uses the right cell's value
 // ------------------------------------------------------------------------------------
 struct AdvectionColor1D {
-    static constexpr int MEQN = 1, MWAVES = 1, NCELL = 2, NAUX = 1;
+    static constexpr int MEQN = 1, MWAVES = 1, NCELL = 2, NAUX = 1, NAUX_T = 1;
+    template <int IXY> __host__ __device__ static constexpr int aux_index(int k) { return k; }
+    template <int IXY> __host__ __device__ static constexpr int auxt_index(int k) { return k; }
     struct Cell { double q[1]; double u; };
     template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
     template <int IXY>
@@ -472,7 +474,9 @@ struct Acoustics2D {
 // ---- 2-D colour equation with edge velocities (third-party rpn2_vc_advection.f / rpt2_vc_advection.f, restated):
 // aux(1) = u at the cell's left edge, aux(2) = v at its bottom edge
 struct VcAdvection2D {
-    static constexpr int MEQN = 1, MWAVES = 1, NAUX = 2;
+    static constexpr int MEQN = 1, MWAVES = 1, NAUX = 2, NAUX_T = 2;
+    template <int IXY> __host__ __device__ static constexpr int aux_index(int k) { return k; }
+    template <int IXY> __host__ __device__ static constexpr int auxt_index(int k) { return k; }
     struct Cell { double q[1]; double u, v; };
     template <int IXY> __device__ static constexpr bool nz(int, int) { return true; }
     template <int IXY>
@@ -496,7 +500,8 @@ struct VcAdvection2D {
     // down-going part: the transverse velocity at this cell's own lower edge; up-going: at the lower edge of the
     // cell above (auxa)
     template <int IXY>
-    __device__ static __forceinline__ void transverse_vc(const Cell &c1, const double * /*auxb*/, const double *auxa,
+    __device__ static __forceinline__ void transverse_vc(const Cell &c1, const double * /*auxo*/, const double * /*auxb*/,
+                                                         const double *auxa, const RpParams &,
                                                          const double (&asdq)[1], double (&bm)[1], double (&bp)[1]) {
         const double own = IXY == 1 ? c1.v : c1.u, above = IXY == 1 ? auxa[1] : auxa[0];
         bm[0] = dmin(own, 0.0) * asdq[0];
@@ -508,7 +513,9 @@ struct VcAdvection2D {
 // formulas of VcAcoustics3D below); q = (p, u, v); aux(1) = Z, aux(2) = c.  The transverse solver
 // (rpt2_vc_acoustics.f, restated) needs the aux values of the two neighbouring slices: transverse_vc.
 struct VcAcoustics2D {
-    static constexpr int MEQN = 3, MWAVES = 2, NAUX = 2;
+    static constexpr int MEQN = 3, MWAVES = 2, NAUX = 2, NAUX_T = 2;
+    template <int IXY> __host__ __device__ static constexpr int aux_index(int k) { return k; }
+    template <int IXY> __host__ __device__ static constexpr int auxt_index(int k) { return k; }
     struct Cell { double q[3]; double z, c; };
     template <int IXY> __device__ static constexpr bool nz(int /*mw*/, int m) { return m == 0 || m == IXY; }
     template <int IXY>
@@ -546,7 +553,8 @@ struct VcAcoustics2D {
     // cells below / above it in the transverse direction.  The down-going part enters the slice below with that
     // slice's impedance and sound speed, the up-going part the slice above.
     template <int IXY>
-    __device__ static __forceinline__ void transverse_vc(const Cell &c1, const double *auxb, const double *auxa,
+    __device__ static __forceinline__ void transverse_vc(const Cell &c1, const double * /*auxo*/, const double *auxb,
+                                                         const double *auxa, const RpParams &,
                                                          const double (&asdq)[3], double (&bm)[3], double (&bp)[3]) {
         constexpr int mu = IXY, mv = (IXY == 1) ? 2 : 1;
         const double zm = auxb[0], zz = c1.z, zp = auxa[0], cm = auxb[1], cp = auxa[1];
@@ -561,7 +569,9 @@ struct VcAcoustics2D {
 // named by the reference's test/acoustics/3d/Makefile) --------------------------------------------------
 // q = (p, u, v, w); aux(1) = Z, aux(2) = c.  DIR = 1,2,3 selects the normal velocity q(DIR).
 struct VcAcoustics3D {
-    static constexpr int MEQN = 4, MWAVES = 2, NAUX = 2;
+    static constexpr int MEQN = 4, MWAVES = 2, NAUX = 2, NAUX_T = 2;
+    template <int IXY> __host__ __device__ static constexpr int aux_index(int k) { return k; }
+    template <int IXY> __host__ __device__ static constexpr int auxt_index(int k) { return k; }
     struct Cell { double q[4]; double z, c; };
     template <int DIR> __device__ static constexpr bool nz(int /*mw*/, int m) { return m == 0 || m == DIR; }
     template <int DIR>
@@ -696,6 +706,225 @@ struct Shallow2D {
             }
             bm[m] = m_; bp[m] = p_;
         }
+    }
+};
+
+
+// ------------------------------------------------------------------------------------
+// Shallow water on the sphere (Calhoun, Helzel & LeVeque 2008), q = (h, hu, hv, hw) with Cartesian momentum;
+// third-party rpn2_shallow_sphere.f / rpt2_shallow_sphere.f (test/shallow_sphere/Makefile:7), restated; same
+// operation order as oracle/classic_oracle.c: rpn2_sphere / rpt2_sphere / sphere_qcor.  par = g, dxcom, dycom.
+// aux (setaux.f:10-25): 0 kappa, 1-3 / 4-6 normal and tangent of the LEFT edge, 7-9 / 10-12 of the BOTTOM edge,
+// 13-15 radial unit vector at the cell centre.  A sweep along IXY needs the edge of that direction + the radial
+// vector (9 components: aux_index); the transverse solves need the OTHER direction's edge + radial vector of the
+// cell itself and of its two neighbours across (auxt_index).
+// ------------------------------------------------------------------------------------
+struct ShallowSphere {
+    static constexpr int MEQN = 4, MWAVES = 3, NAUX = 9, NAUX_T = 9;
+    static constexpr bool HAS_QCOR = true;   // the app replaces step2.f by step2qcor.f (Makefile:16)
+    template <int IXY> __host__ __device__ static constexpr int aux_index(int k) {
+        return k < 6 ? (IXY == 1 ? 1 + k : 7 + k) : 13 + (k - 6);
+    }
+    template <int IXY> __host__ __device__ static constexpr int auxt_index(int k) {
+        return k < 6 ? (IXY == 1 ? 7 + k : 1 + k) : 13 + (k - 6);
+    }
+    struct Cell {
+        double q[4];
+        double er[3];          // radial unit vector of the cell
+        double hs, sgh;        // sqrt(h), sqrt(g*h)
+        double en[3], et[3];   // unit normal / unit tangent of the cell's own left (IXY 1) or bottom (IXY 2) edge
+        double gam;            // length of that edge
+    };
+    template <int IXY> __device__ static constexpr bool nz(int mw, int m) { return !(mw == 1 && m == 0); }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &par, const double *auxv) {
+        Cell c;
+        for (int m = 0; m < 4; m++) c.q[m] = q[m];
+        for (int k = 0; k < 3; k++) { c.en[k] = auxv[k]; c.er[k] = auxv[6 + k]; }
+        const double etx = auxv[3], ety = auxv[4], etz = auxv[5];
+        c.gam = dsqrt(etx * etx + ety * ety + etz * etz);
+        const Recip by_gam(c.gam);
+        c.et[0] = by_gam.div(etx); c.et[1] = by_gam.div(ety); c.et[2] = by_gam.div(etz);
+        c.hs = dsqrt(q[0]);
+        c.sgh = dsqrt(par.v[0] * q[0]);
+        return c;
+    }
+    struct Roe { double u, v, a, hunl, hunr, hutl, hutr; };
+    // L = qr(i-1) (the reference's suffix "r"), R = ql(i) (suffix "l"); the edge belongs to R
+    __device__ static __forceinline__ Roe roe(const Cell &L, const Cell &R, double g) {
+        Roe r;
+        r.hunl = R.en[0] * R.q[1] + R.en[1] * R.q[2] + R.en[2] * R.q[3];
+        r.hunr = R.en[0] * L.q[1] + R.en[1] * L.q[2] + R.en[2] * L.q[3];
+        r.hutl = R.et[0] * R.q[1] + R.et[1] * R.q[2] + R.et[2] * R.q[3];
+        r.hutr = R.et[0] * L.q[1] + R.et[1] * L.q[2] + R.et[2] * L.q[3];
+        const double h = (L.q[0] + R.q[0]) * 0.50;
+        const Recip by_hsq(L.hs + R.hs);
+        r.u = by_hsq.div(fdiv(r.hunr, L.hs) + fdiv(r.hunl, R.hs));
+        r.v = by_hsq.div(fdiv(r.hutr, L.hs) + fdiv(r.hutl, R.hs));
+        r.a = dsqrt(g * h);
+        return r;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &par, double (&s)[3]) {
+        const double dy = IXY == 1 ? par.v[2] : par.v[1];
+        const Roe r = roe(L, R, par.v[0]);
+        const Recip by_dy(dy);
+        s[0] = by_dy.div((r.u - r.a) * R.gam);
+        s[1] = by_dy.div(r.u * R.gam);
+        s[2] = by_dy.div((r.u + r.a) * R.gam);
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &par,
+                                                 double (&wave)[3][4], double (&s)[3], double (&amdq)[4],
+                                                 double (&apdq)[4]) {
+        const double g = par.v[0];
+        const double dy = IXY == 1 ? par.v[2] : par.v[1];
+        const Recip by_dy(dy);
+        const Roe r = roe(L, R, g);
+        const double u = r.u, v = r.v, a = r.a, gamma = R.gam;
+        const double delta1 = R.q[0] - L.q[0];
+        const double delta2 = r.hunl - r.hunr;
+        const double delta3 = r.hutl - r.hutr;
+        const double hba = fdiv(0.50, a);
+        const double a1 = ((u + a) * delta1 - delta2) * hba;
+        const double a2 = -v * delta1 + delta3;
+        const double a3 = (-(u - a) * delta1 + delta2) * hba;
+        wave[0][0] = a1;
+        wave[1][0] = 0.0;
+        wave[2][0] = a3;
+        for (int k = 0; k < 3; k++) {
+            wave[0][1 + k] = a1 * (u - a) * R.en[k] + a1 * v * R.et[k];
+            wave[1][1 + k] = a2 * R.et[k];
+            wave[2][1 + k] = a3 * (u + a) * R.en[k] + a3 * v * R.et[k];
+        }
+        s[0] = by_dy.div((u - a) * gamma);
+        s[1] = by_dy.div(u * gamma);
+        s[2] = by_dy.div((u + a) * gamma);
+
+        // Harten-Hyman entropy fix; the Fortran's early exits become flags
+        for (int m = 0; m < 4; m++) amdq[m] = 0.0;
+        const double s0 = by_dy.div((fdiv(r.hunr, L.q[0]) - L.sgh) * gamma);
+        bool done = (s0 > 0.0) && (s[0] > 0.0);
+        {
+            const double h1 = L.q[0] + wave[0][0];
+            const double hu1 = r.hunr + R.en[0] * wave[0][1] + R.en[1] * wave[0][2] + R.en[2] * wave[0][3];
+            const double s1 = by_dy.div((fdiv(hu1, h1) - dsqrt(g * h1)) * gamma);
+            double sfract;
+            if (s0 < 0.0 && s1 > 0.0) sfract = s0 * fdiv(s1 - s[0], s1 - s0);
+            else if (s[0] < 0.0) sfract = s[0];
+            else sfract = 0.0;
+            if (!done)
+                for (int m = 0; m < 4; m++) amdq[m] = sfract * wave[0][m];
+        }
+        done = done || (s[1] > 0.0);
+        {
+            const double s03 = by_dy.div((fdiv(r.hunl, R.q[0]) + R.sgh) * gamma);
+            const double h3 = R.q[0] - wave[2][0];
+            const double hu3 = r.hunl - (R.en[0] * wave[2][1] + R.en[1] * wave[2][2] + R.en[2] * wave[2][3]);
+            const double s3 = by_dy.div((fdiv(hu3, h3) + dsqrt(g * h3)) * gamma);
+            double sfract = 0.0;
+            bool add = true;
+            if (s3 < 0.0 && s03 > 0.0) sfract = s3 * fdiv(s03 - s[2], s03 - s3);
+            else if (s[2] < 0.0) sfract = s[2];
+            else add = false;
+            if (!done) {
+                for (int m = 1; m < 4; m++) amdq[m] = amdq[m] + s[1] * wave[1][m];
+                if (add)
+                    for (int m = 0; m < 4; m++) amdq[m] = amdq[m] + sfract * wave[2][m];
+            }
+        }
+        for (int m = 0; m < 4; m++) {
+            double df = s[0] * wave[0][m];
+            if (m > 0) df = df + s[1] * wave[1][m];
+            df = df + s[2] * wave[2][m];
+            apdq[m] = df - amdq[m];
+        }
+        // project the momentum parts onto the tangent plane of the cell each fluctuation enters
+        const double amn = L.er[0] * amdq[1] + L.er[1] * amdq[2] + L.er[2] * amdq[3];
+        const double apn = R.er[0] * apdq[1] + R.er[1] * apdq[2] + R.er[2] * apdq[3];
+        for (int k = 0; k < 3; k++) {
+            amdq[1 + k] = amdq[1 + k] - amn * L.er[k];
+            apdq[1 + k] = apdq[1 + k] - apn * R.er[k];
+        }
+    }
+    // asdq sits in cell c1; auxo / auxb / auxa = (other-direction edge normal 0-2, tangent 3-5, radial vector 6-8) of
+    // that cell and of its neighbours below / above.  Up-going: the edge ABOVE the cell (the neighbour's own edge),
+    // tangent plane of the cell above; down-going: the cell's own edge, tangent plane of the cell below.
+    template <int IXY>
+    __device__ static __forceinline__ void transverse_vc(const Cell &c1, const double *auxo, const double *auxb,
+                                                         const double *auxa, const RpParams &par,
+                                                         const double (&asdq)[4], double (&bm)[4], double (&bp)[4]) {
+        const double g = par.v[0];
+        const double dx = IXY == 1 ? par.v[1] : par.v[2];
+        const Recip by_dx(dx);
+        const double h = c1.q[0];
+        const double a = c1.sgh;
+        const double hba = fdiv(0.50, a);
+        const Recip by_h(h);
+#pragma unroll
+        for (int up = 1; up >= 0; up--) {
+            const double *ae = up ? auxa : auxo;
+            const double *ap = up ? auxa : auxb;
+            const double enx = ae[0], eny = ae[1], enz = ae[2];
+            double etx = ae[3], ety = ae[4], etz = ae[5];
+            const double gamma = dsqrt(etx * etx + ety * ety + etz * etz);
+            const Recip by_gam(gamma);
+            etx = by_gam.div(etx); ety = by_gam.div(ety); etz = by_gam.div(etz);
+            const double u = by_h.div(enx * c1.q[1] + eny * c1.q[2] + enz * c1.q[3]);
+            const double v = by_h.div(etx * c1.q[1] + ety * c1.q[2] + etz * c1.q[3]);
+            const double delta1 = asdq[0];
+            const double delta2 = enx * asdq[1] + eny * asdq[2] + enz * asdq[3];
+            const double delta3 = etx * asdq[1] + ety * asdq[2] + etz * asdq[3];
+            const double a1 = ((u + a) * delta1 - delta2) * hba;
+            const double a2 = -v * delta1 + delta3;
+            const double a3 = (-(u - a) * delta1 + delta2) * hba;
+            const double en[3] = {enx, eny, enz}, et[3] = {etx, ety, etz};
+            double wb[3][4], sb[3];
+            wb[0][0] = a1; wb[1][0] = 0.0; wb[2][0] = a3;
+            for (int k = 0; k < 3; k++) {
+                wb[0][1 + k] = a1 * (u - a) * en[k] + a1 * v * et[k];
+                wb[1][1 + k] = a2 * et[k];
+                wb[2][1 + k] = a3 * (u + a) * en[k] + a3 * v * et[k];
+            }
+            sb[0] = by_dx.div((u - a) * gamma);
+            sb[1] = by_dx.div(u * gamma);
+            sb[2] = by_dx.div((u + a) * gamma);
+            double out[4];
+            for (int m = 0; m < 4; m++) {
+                double acc = 0.0;
+                for (int mw = 0; mw < 3; mw++)
+                    acc = acc + (up ? dmax(sb[mw], 0.0) : dmin(sb[mw], 0.0)) * wb[mw][m];
+                out[m] = acc;
+            }
+            const double bn = ap[6] * out[1] + ap[7] * out[2] + ap[8] * out[3];
+            for (int k = 0; k < 3; k++) out[1 + k] = out[1 + k] - bn * ap[6 + k];
+            for (int m = 0; m < 4; m++) {
+                if (up) bp[m] = out[m];
+                else bm[m] = out[m];
+            }
+        }
+    }
+    // qcor.f:1-72: el / er = raw (normal 0-2, tangent 3-5) of the cell's own edge and of the next cell's edge along the
+    // sweep, rad = the cell's radial vector
+    template <int IXY>
+    __device__ static __forceinline__ void qcor(const double *q, const double *el, const double *er_, const double *rad,
+                                                const RpParams &par, double (&qc)[4]) {
+        const double g = par.v[0];
+        const double dy = IXY == 1 ? par.v[2] : par.v[1];
+        const double gammal = fdiv_ieee(dsqrt(el[3] * el[3] + el[4] * el[4] + el[5] * el[5]), dy);
+        const double enxl = el[0] * gammal, enyl = el[1] * gammal, enzl = el[2] * gammal;
+        const double gammar = fdiv_ieee(dsqrt(er_[3] * er_[3] + er_[4] * er_[4] + er_[5] * er_[5]), dy);
+        const double enxr = er_[0] * gammar, enyr = er_[1] * gammar, enzr = er_[2] * gammar;
+        const double q1 = q[0], q2 = q[1], q3 = q[2], q4 = q[3];
+        const Recip by_q1(q1);
+        const double hg = 0.5 * g * (q1 * q1);
+        const double dx_ = enxr - enxl, dy_ = enyr - enyl, dz_ = enzr - enzl;
+        qc[0] = dx_ * q2 + dy_ * q3 + dz_ * q4;
+        qc[1] = dx_ * (by_q1.div(q2 * q2) + hg) + dy_ * by_q1.div(q2 * q3) + dz_ * by_q1.div(q2 * q4);
+        qc[2] = dx_ * by_q1.div(q2 * q3) + dy_ * (by_q1.div(q3 * q3) + hg) + dz_ * by_q1.div(q3 * q4);
+        qc[3] = dx_ * by_q1.div(q2 * q4) + dy_ * by_q1.div(q3 * q4) + dz_ * (by_q1.div(q4 * q4) + hg);
+        const double qcn = rad[0] * qc[1] + rad[1] * qc[2] + rad[2] * qc[3];
+        for (int k = 0; k < 3; k++) qc[1 + k] = qc[1 + k] - qcn * rad[k];
     }
 };
 

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, i
         for (int m = 0; m < MEQN; m++) tile[stile_at<IXY>(m, al, ac)] = a.qin[m * a.plane + g];
         if constexpr (CAPA) tile[stile_at<IXY>(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
 #pragma unroll
-        for (int m = 0; m < NAUX; m++) tile[stile_at<IXY>(PAUX + m, al, ac)] = a.aux[m * a.plane + g];
+        for (int m = 0; m < NAUX; m++) tile[stile_at<IXY>(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + g];
     }
     __syncthreads();
 

@@ -55,7 +55,7 @@ struct SweepArgs {
     // unsplit algorithm (step2.f) only:
     int trans;        // method(3): 0 no transverse terms, 1 increment waves, 2 + correction waves
     double dtd_t;     // dt/d of the transverse direction
-    double *scr[5];   // per-slice pieces, combined in the reference's order by combine_kernel
+    double *scr[6];   // per-slice pieces, combined in the reference's order by combine_kernel ([5]: dt/d * qcor)
 };
 
 // Pointers for the unsplit combine pass (step2.f:130-137,214-218 accumulation order)
@@ -63,10 +63,11 @@ struct CombineArgs {
     const double *qold;
     double *qnew;
     const double *aux;
-    const double *x[5];  // x slices: qadd, dtdx*df (or S with capa), dtdy*dg, dtdy*gadd1, dtdy*gadd2
-    const double *y[4];  // y slices: mid (or qadd with capa), S (capa only), dtdx*gadd1, dtdx*gadd2
+    const double *x[6];  // x slices: qadd, dtdx*df (or S with capa), dtdy*dg, dtdy*gadd1, dtdy*gadd2, dtdx*qcor
+    const double *y[5];  // y slices: mid (or qadd with capa), S (capa only), dtdx*gadd1, dtdx*gadd2, dtdy*qcor
     long pitch, plane;
     int I, J, mbc, mx, my, mcapa, meqn;
+    int qcor;            // step2qcor.f instead of step2.f (shallow water on the sphere)
 };
 
 struct RkLaunch {

@@ -10,8 +10,9 @@ the string ``'euler_5wave_2d'``); ``cparam`` lists the aux_global keys in common
 
 
 class RiemannSolver(object):
-    def __init__(self, name, rp_id, ndim, meqn, mwaves, cparam, has_transverse=False):
+    def __init__(self, name, rp_id, ndim, meqn, mwaves, cparam, has_transverse=False, grid_params=False):
         self.name = name
+        self.grid_params = grid_params     # append the grid spacings (the reference app sets comxyt.dxcom/dycom)
         self.id = rp_id
         self.ndim = ndim
         self.meqn = meqn
@@ -26,6 +27,14 @@ class RiemannSolver(object):
                                    block in the Riemann solver have not been 
                                    set in aux_global.""")
         return [float(aux_global[k]) for k in self.cparam]
+
+    def all_params(self, state):
+        """cparam values, then dx, dy(, dz) for solvers that read common /comxyt/ (set by the reference app:
+        apps/shallow-sphere/shallow_4_Rossby_Haurwitz_wave.py:449-451)."""
+        p = self.params(state.aux_global)
+        if self.grid_params:
+            p = p + [float(d) for d in state.grid.d]
+        return p
 
     def __repr__(self):
         return "<RiemannSolver %s>" % self.name
@@ -43,12 +52,15 @@ rp_vc_acoustics_2d = RiemannSolver("vc_acoustics_2d", 14, 2, 3, 2, [], True)    
 rp_vc_advection_2d = RiemannSolver("vc_advection_2d", 15, 2, 1, 1, [], True)     # aux(1)=u at left edge, aux(2)=v at bottom edge
 rp_acoustics_2d = RiemannSolver("acoustics_2d", 10, 2, 3, 2, ["rho", "bulk", "cc", "zz"], True)
 rp_euler_5wave_2d = RiemannSolver("euler_5wave_2d", 11, 2, 5, 5, ["gamma", "gamma1"], True)
+# rpn2/rpt2_shallow_sphere (apps/shallow-sphere/Makefile:7): common /sw/ g; the 16 aux components of setaux.f; the
+# unsplit step is the app's step2qcor.f
+rp_shallow_sphere_2d = RiemannSolver("shallow_sphere_2d", 16, 2, 4, 3, ["g"], True, grid_params=True)
 
 # 3-D acoustics, impedance and sound speed per cell in aux(1), aux(2) (test/acoustics/3d/Makefile:
 # rpn3_vc_acoustics.f; the transverse rpt3/rptt3 of the unsplit algorithm are not built: dim_split only)
 rp_vc_acoustics_3d = RiemannSolver("vc_acoustics_3d", 20, 3, 4, 2, [])
 
-_ALL = [rp_advection_1d, rp_acoustics_1d, rp_advection_color_1d, rp_burgers_1d, rp_euler_1d, rp_shallow_1d, rp_advection_2d, rp_shallow_2d, rp_vc_acoustics_2d, rp_vc_advection_2d, rp_acoustics_2d, rp_euler_5wave_2d, rp_vc_acoustics_3d]
+_ALL = [rp_advection_1d, rp_acoustics_1d, rp_advection_color_1d, rp_burgers_1d, rp_euler_1d, rp_shallow_1d, rp_advection_2d, rp_shallow_2d, rp_vc_acoustics_2d, rp_vc_advection_2d, rp_acoustics_2d, rp_euler_5wave_2d, rp_shallow_sphere_2d, rp_vc_acoustics_3d]
 BY_NAME = dict((r.name, r) for r in _ALL)
 
 

@@ -218,7 +218,7 @@ class SharpClawSolver(Solver):
         rp = riemann.get(self.rp)
         if rp.ndim != self.ndim or rp.mwaves != self.mwaves or rp.meqn != state.meqn:
             raise Exception("Riemann solver %s does not match ndim/mwaves/meqn of the problem" % rp.name)
-        params = rp.params(state.aux_global)
+        params = rp.all_params(state)
 
         self._release()
         cfg = _lib.Config()

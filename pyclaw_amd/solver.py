@@ -56,6 +56,17 @@ class ConstantStateBC(DeviceBC):
         _lib.check(_lib.lib().pcl_bc_const(solver._h, idim, side, _lib.d(self.state)))
 
 
+class SphereMirrorBC(DeviceBC):
+    """The custom y boundary of the shallow-water-on-the-sphere app (``qbc_lower_y`` / ``qbc_upper_y``,
+    apps/shallow-sphere/shallow_4_Rossby_Haurwitz_wave.py:295-313): ghost row j takes interior row 2*mbc-1-j with
+    the x index reversed over the whole ghosted width, on the device."""
+
+    def apply(self, solver, idim, side):
+        if idim != 1:
+            raise Exception("SphereMirrorBC is the y boundary of a 2-D grid")
+        _lib.check(_lib.lib().pcl_bc(solver._h, idim, side, 4))
+
+
 class Solver(object):
     r"""Pyclaw solver superclass; see the reference docstring (solver.py:25-125)."""
 

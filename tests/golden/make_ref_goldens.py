@@ -6,6 +6,8 @@ under /root/reference, oracle/Makefile) for the paths the reference ships no gol
   ref_step2_unsplit.npz    step2.f  (unsplit, method(3) = 0, 1, 2; rpt2_euler_5wave_rec_loc.f)
   ref_step2ds_capa.npz     step2ds.f with a capacity function (mcapa = 2), ids = 1, 2
   ref_sharp_flux2.npz      SharpClaw flux2.f90, lim_type 2 (PyWENO weno5) and 3 (legacy weno5)
+  ref_step2_unsplit_capa.npz  step2.f with a capacity function (mcapa = 2), method(3) = 0, 1, 2
+  ref_sphere_setup.npz     the shallow-sphere app's own setaux.f / qinit.f / src2.f / qcor.f (40 x 20 grid)
 
 Only inputs' SEEDS and the outputs are stored (inputs are regenerated from the seed by the tests).  Run in the
 build container (needs oracle/_ref, i.e. the reference tree): python tests/golden/make_ref_goldens.py
@@ -68,6 +70,38 @@ def main():
         out["q_ids%d" % ids] = qn
         out["cfl_ids%d" % ids] = cfl
     np.savez_compressed(os.path.join(HERE, "ref_step2ds_capa.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
+
+    # unsplit algorithm WITH a capacity function (the annulus / sphere configuration): step2.f:145-152,227-234
+    out = {}
+    for trans in (0, 1, 2):
+        q0 = euler_state(40 + trans, shape)
+        aux = capa_field(40 + trans, shape)
+        qn = q0.copy("F")
+        method = np.array([1, 2, trans, 0, 0, 2, 2], dtype=np.int32)
+        _, cfl = ref.step2(O.RP_EULER5_2D, PAR, max(mx, my), mbc, mx, my, q0.copy("F"), qn, aux, dx, dy, dt, method, MTH)
+        out["q_trans%d" % trans] = qn
+        out["cfl_trans%d" % trans] = cfl
+    np.savez_compressed(os.path.join(HERE, "ref_step2_unsplit_capa.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
+
+    # shallow water on the sphere: the app's own data generators and source / correction terms
+    sp = O.RefSphereProblem()
+    smx, smy, g = 40, 20, 2
+    sdx, sdy = 4.0 / smx, 2.0 / smy
+    aux = sp.sphere_setaux(g, smx, smy, -3.0, -1.0, sdx, sdy)
+    q0 = sp.sphere_qinit(g, smx, smy, -3.0, -1.0, sdx, sdy)
+    qi = np.array(q0[:, g:-g, g:-g], order="F")
+    qs = qi.copy(order="F")
+    sp.sphere_src2(qs, np.array(aux[:, g:-g, g:-g], order="F"), -3.0, -1.0, sdx, sdy, 0.01)
+    qc = np.zeros((2, 4, 8))
+    for ixy in (1, 2):
+        for k in range(8):           # qcor at 8 cells of one slice (Fortran indices 3 .. 10)
+            if ixy == 1:
+                a1, q1 = np.array(aux[:, :, 7], order="F"), np.array(q0[:, :, 7], order="F")
+            else:
+                a1, q1 = np.array(aux[:, 9, :], order="F"), np.array(q0[:, 9, :], order="F")
+            qc[ixy - 1, :, k] = sp.qcor(ixy, 3 + k, a1, q1, g, 11489.57219, sdx, sdy)
+    np.savez_compressed(os.path.join(HERE, "ref_sphere_setup.npz"), mx=smx, my=smy, aux=aux, q0=qi, q_src2=qs,
+                        dt_src2=0.01, qcor=qc)
 
     sref = O.RefSharp2DEuler()
     mbc = 3

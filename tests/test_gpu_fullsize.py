@@ -168,9 +168,9 @@ def test_c2_acoustics_1024_unsplit_spot_parity_and_shift(coracle):
     assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
 
 
-def test_c5_grid_sharpclaw_2048x1024_spot_parity(coracle):
-    """SharpClaw WENO5 right-hand side (flux2.f90) on the C5 grid size with a capacity function in aux
-    (the C5 Riemann solver itself, rpn2_shallow_sphere, is third-party and not built: Euler stands in)."""
+def test_sharpclaw_capa_euler_2048x1024_spot_parity(coracle):
+    """SharpClaw WENO5 right-hand side (flux2.f90) with a capacity function at the C5 grid size, Euler solver.  (The C5
+    configuration itself -- the sphere solver with its 16 aux components -- is tests/test_gpu_sphere.py.)"""
     from pyclaw_amd import _lib as L
     lib = L.lib()
     nx, ny = 2048, 1024

@@ -1,6 +1,7 @@
 """
 Goldens generated from the REFERENCE'S OWN FORTRAN (flang build, tests/golden/make_ref_goldens.py) for the paths
-the reference ships no golden for -- unsplit step2.f (method(3) = 0/1/2), step2ds.f with a capacity function,
+the reference ships no golden for -- unsplit step2.f (method(3) = 0/1/2, with and without a capacity function),
+step2ds.f with a capacity function,
 SharpClaw flux2.f90 (lim_type 2 and 3).  CPU: the oracle's C restatement must reproduce them bit for bit;
 GPU (-m gpu): the HIP path, through the C ABI, must too.  Unlike tests/test_oracle_vs_ref.py these do not need
 oracle/_ref at test time.
@@ -61,7 +62,36 @@ def test_oracle_sharp_flux2(coracle, lim):
     assert np.array_equal(dq[:, 3:-3, 3:-3], z["dq_lim%d" % lim]) and cfl == float(z["cfl_lim%d" % lim])
 
 
+@pytest.mark.parametrize("trans", [0, 1, 2])
+def test_oracle_step2_unsplit_capa(coracle, trans):
+    """unsplit step2.f WITH a capacity function (step2.f:145-152,227-234: the annulus / sphere configuration)"""
+    z = load("ref_step2_unsplit_capa.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 2)
+    q0, aux = G.euler_state(40 + trans, shape), G.capa_field(40 + trans, shape)
+    qn = q0.copy("F")
+    method = np.array([1, 2, trans, 0, 0, 2, 2], dtype=np.int32)
+    _, cfl = coracle.step2(O.RP_EULER5_2D, G.PAR, max(mx, my), 2, mx, my, q0.copy("F"), qn, aux, dx, dy, dt, method, G.MTH)
+    assert np.array_equal(qn, z["q_trans%d" % trans]) and cfl == float(z["cfl_trans%d" % trans])
+
+
 # ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("trans", [0, 1, 2])
+def test_hip_step2_unsplit_capa(trans):
+    from pyclaw_amd import _lib as L
+    z = load("ref_step2_unsplit_capa.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 2)
+    q0, aux = G.euler_state(40 + trans, shape), G.capa_field(40 + trans, shape)
+    out = q0.copy("F")
+    method = np.array([1, 2, trans, 0, 0, 2, 2], dtype=np.int32)
+    mth = np.array(G.MTH, dtype=np.int32)
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(np.array(G.PAR)), 0, 5, 5, 2, 2, mx, my, L.d(q0), L.d(out), L.d(aux),
+                              dx, dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None), slice(2, -2), slice(2, -2))
+    assert np.array_equal(out[inner], z["q_trans%d" % trans][inner]) and cfl.value == float(z["cfl_trans%d" % trans])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("trans", [0, 1, 2])
 def test_hip_step2_unsplit(trans):
