@@ -53,6 +53,8 @@ extern "C" {
 #define PCL_RP_EULER_1D 4       /* rp1_euler_with_efix.f          cparam: gamma,gamma1            */
 #define PCL_RP_SHALLOW_1D 5     /* rp1_shallow_roe_with_efix.f    cparam: g                       */
 #define PCL_RP_ADVECTION_COLOR_1D 6 /* rp1_advection_color.f; aux(1) = velocity at the cell's left edge */
+#define PCL_RP_ELASTICITY_FWAVE_1D 7 /* rp1_nonlinear_elasticity_fwave.f (stegoton); F-WAVE solver: fwave = 1;  */
+                                     /* aux(1)=rho, aux(2)=K, aux(3)=1: sigma=K eps, else exp(K eps)-1          */
 #define PCL_RP_ACOUSTICS_2D 10 /* rpn2/rpt2_acoustics.f     cparam: rho,bulk,cc,zz      */
 #define PCL_RP_EULER5_2D 11    /* rpn2/rpt2_euler_5wave.f   cparam: gamma,gamma1        */
 #define PCL_RP_ADVECTION_2D 12  /* rpn2/rpt2_advection.f      cparam: u,v                  */
@@ -62,6 +64,7 @@ extern "C" {
 #define PCL_RP_SHALLOW_SPHERE_2D 16 /* rpn2/rpt2_shallow_sphere.f (apps/shallow-sphere/Makefile:7); common /sw/ g + comxyt dxcom,dycom */
                                     /* -> rp_params g, dx, dy; aux = the 16 components of apps/shallow-sphere/setaux.f:10-25;      */
                                     /* the unsplit step follows the app's step2qcor.f (conservation fix qcor.f) instead of step2.f */
+#define PCL_RP_PSYSTEM_FWAVE_2D 17 /* rpn2/rpt2_psystem.f (test/psystem/Makefile:5); F-WAVE solver: fwave = 1; aux as above + aux(4)=eps */
 #define PCL_RP_VC_ACOUSTICS_3D 20 /* rpn3_vc_acoustics.f (test/acoustics/3d/Makefile); aux(1)=Z, aux(2)=c; dim-split only */
 
 /* boundary condition types = pyclaw.BC (src/pyclaw/solver.py:17-23) */
@@ -111,7 +114,8 @@ typedef struct pcl_config {
     int device;                     /* HIP device ordinal                                  */
     int math;                       /* PCL_MATH_*                                          */
     int kind;                       /* PCL_KIND_CLASSIC | PCL_KIND_SHARPCLAW               */
-    int lim_type;                   /* SharpClaw: 2 = WENO5 (PyWENO form), 3 = legacy WENO5 */
+    int lim_type;                   /* SharpClaw: 1 = tvd2 (reconstruct.f90:568-625; mthlim per COMPONENT),     */
+                                    /*            2 = WENO5 (PyWENO form), 3 = legacy WENO5                      */
 } pcl_config;
 
 /* ---- library ---------------------------------------------------------------------- */
@@ -126,6 +130,12 @@ int pcl_device_count(void);                     /* never initialises a context  
 int pcl_step1(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx,
               double *q, const double *aux, double dx, double dt, const int *method,
               const int *mthlim, double *cfl);
+
+/* classic1fw.step1(...) -> (q,cfl): the f-wave twin, src/fortran/1d/classic/step1fw.f (clawpack.py:221-222 picks the
+ * module name + 'fw' when solver.fwave is set); rp must be an f-wave solver. */
+int pcl_step1fw(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx,
+                double *q, const double *aux, double dx, double dt, const int *method,
+                const int *mthlim, double *cfl);
 
 /* classic2.step2ds(maxm,mbc,mx,my,qold,qnew,aux,dx,dy,dt,method,mthlim,aux1,aux2,aux3,work,ids)
  * -> (qnew,cfl)   step2ds.f:2-5, clawpack.py:538-544.  qold may alias qnew.  The work
@@ -154,6 +164,9 @@ int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux,
  * q and dq are (meqn, mx+2mbc[, my+2mbc]) with mbc = 3 (weno_order 5); dq's interior receives
  * dt*dq/dt, its ghost cells are zeroed.  The F90 module state the reference sets through
  * clawparams/workspace/reconstruct (lim_type, mcapa, dx, mwaves) is passed explicitly. */
+/* clawparams.mthlim, part of the F90 module state the reference sets before calling flux1/flux2
+ * (sharpclaw.py:268); read by lim_type = 1 (tvd2) only, indexed by component.  Default: all 1 (minmod). */
+int pcl_sharp_module_mthlim(const int *mthlim, int n);
 int pcl_sharp_flux1(int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux, int mcapa,
                     int mbc, int mx, const double *q, double *dq, const double *aux, double dx, double dt,
                     double *cfl);

@@ -55,7 +55,9 @@
 #define RP_SHALLOW_2D 13
 #define RP_VC_ACOUSTICS_2D 14
 #define RP_VC_ADVECTION_2D 15
+#define RP_ELASTICITY_FWAVE_1D 7
 #define RP_SHALLOW_SPHERE_2D 16
+#define RP_PSYSTEM_FWAVE_2D 17
 #define RP_VC_ACOUSTICS_3D 20
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
@@ -723,6 +725,88 @@ static void sphere_qcor(int ixy, int i, const double *aux, int maux, const doubl
 static int orc_qcor_on = 0;
 void orc_set_qcor(int on) { orc_qcor_on = on; }
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * f-wave Riemann solvers (flux2fw.f / step1fw.f take the jump in the FLUX split into waves).  Both are THIRD-PARTY
+ * (clawpack/riemann: rp1_nonlinear_elasticity_fwave.f named by apps/elasticity/1d/stegoton/Makefile, rpn2_psystem.f /
+ * rpt2_psystem.f by test/psystem/Makefile:5), absent from the reference tree and pinned by no golden (the
+ * reference's own psystem verifier returns True, test/test_examples.py:437-441): restated from the published
+ * eigen-structure, PARITY UNPINNED at the solver boundary.  The f-wave PATH (flux2fw.f:151-152, step1fw.f:135-141)
+ * is in the tree and is what these solvers exercise.
+ *   eps_t - (m/rho)_x = 0,  m_t - sigma(eps, x)_x = 0     (2-D: + the same in y for the second momentum)
+ *   stress law per cell: aux(3) == 1: sigma = K eps (linear);  otherwise sigma = exp(K eps) - 1 (LeVeque & Yong 2003;
+ *   the reference apps: stegoton.py:12-13 / psystem.py:108, setaux aux(1) = rho, aux(2) = K [, aux(3) = flag])
+ * Interface i, left cell i-1 (suffix m), right cell i:  c = sqrt(sigma'/rho), Z = rho c,
+ *   b1 = -(Z_i du + dsig)/(Z_m + Z_i)  on (1, Z_m) at speed -c_m,   b2 = -(Z_m du - dsig)/(Z_m + Z_i) on (1, -Z_i) at +c_i.
+ * ------------------------------------------------------------------------------------------------------------ */
+static inline double ps_sigma(double eps, double K, double lin) { return lin == 1.0 ? K * eps : exp(K * eps) - 1.0; }
+static inline double ps_sigmap(double eps, double K, double lin) { return lin == 1.0 ? K : K * exp(K * eps); }
+
+static void rp_fwave_normal(int mu, int meqn, int mwaves, int mbc, int mx, const double *ql, const double *qr,
+                            double *fwave, double *s, double *amdq, double *apdq)
+{
+    const double *auxl = orc_aux1d, *auxr = orc_auxr1d ? orc_auxr1d : orc_aux1d;
+    const int maux = orc_maux1d;
+    double *wave = fwave;
+#define AXL(ma, i) auxl[((ma)-1) + maux * IX(i)]
+#define AXR(ma, i) auxr[((ma)-1) + maux * IX(i)]
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const double rhoi = AXL(1, i), rhoim = AXR(1, i - 1);
+        const double epsi = A2(ql, 1, i), epsim = A2(qr, 1, i - 1);
+        const double urhoi = A2(ql, mu, i), urhoim = A2(qr, mu, i - 1);
+        const double bulki = ps_sigmap(epsi, AXL(2, i), AXL(3, i));
+        const double bulkim = ps_sigmap(epsim, AXR(2, i - 1), AXR(3, i - 1));
+        const double ci = sqrt(bulki / rhoi), cim = sqrt(bulkim / rhoim);
+        const double zi = ci * rhoi, zim = cim * rhoim;
+        const double du = urhoi / rhoi - urhoim / rhoim;
+        const double dsig = ps_sigma(epsi, AXL(2, i), AXL(3, i)) - ps_sigma(epsim, AXR(2, i - 1), AXR(3, i - 1));
+        const double b1 = -(zi * du + dsig) / (zim + zi);
+        const double b2 = -(zim * du - dsig) / (zim + zi);
+        for (int m = 1; m <= meqn; m++) { W(m, 1, i) = 0.0; W(m, 2, i) = 0.0; }
+        W(1, 1, i) = b1;
+        W(mu, 1, i) = b1 * zim;
+        S(1, i) = -cim;
+        W(1, 2, i) = b2;
+        W(mu, 2, i) = b2 * (-zi);
+        S(2, i) = ci;
+        for (int m = 1; m <= meqn; m++) {
+            A2(amdq, m, i) = W(m, 1, i);
+            A2(apdq, m, i) = W(m, 2, i);
+        }
+    }
+#undef AXL
+#undef AXR
+}
+
+/* transverse solver of the p-system: asdq sits in cell i1 = i-2+imp; the down-going part enters the row below with
+ * ITS impedance and speed, the up-going part the row above.  The rows' strains come from aux(4) (the app copies
+ * q(1) there before each step: psystem.py:96-99, "required in rptpv.f").  asdq = b1 (1,0,Z_m) + b3 (1,0,-Z_p). */
+static void rpt2_psystem(int ixy, int imp, int meqn, int mbc, int mx, const double *asdq, double *bmasdq,
+                         double *bpasdq)
+{
+    const int maux = orc_maux1d;
+    const double *aux1 = orc_auxb1d, *aux3 = orc_auxa1d;
+#define AXN(arr, ma, i) arr[((ma)-1) + maux * IX(i)]
+    const int mu = ixy + 1, mv = (ixy == 1) ? 3 : 2;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const int i1 = i - 2 + imp;
+        const double rhom = AXN(aux1, 1, i1), rhop = AXN(aux3, 1, i1);
+        const double bulkm = ps_sigmap(AXN(aux1, 4, i1), AXN(aux1, 2, i1), AXN(aux1, 3, i1));
+        const double bulkp = ps_sigmap(AXN(aux3, 4, i1), AXN(aux3, 2, i1), AXN(aux3, 3, i1));
+        const double cm = sqrt(bulkm / rhom), cp = sqrt(bulkp / rhop);
+        const double zm = cm * rhom, zp = cp * rhop;
+        const double b1 = (A2(asdq, mv, i) + zp * A2(asdq, 1, i)) / (zm + zp);
+        const double b3 = (zm * A2(asdq, 1, i) - A2(asdq, mv, i)) / (zm + zp);
+        A2(bmasdq, 1, i) = -cm * b1;
+        A2(bmasdq, mu, i) = 0.0;
+        A2(bmasdq, mv, i) = -cm * b1 * zm;
+        A2(bpasdq, 1, i) = cp * b3;
+        A2(bpasdq, mu, i) = 0.0;
+        A2(bpasdq, mv, i) = cp * b3 * (-zp);
+    }
+#undef AXN
+}
+
 /* 2-D acoustics normal solver, restated (third-party rpn2_acoustics.f) */
 static void rpn2_acoustics(int ixy, int meqn, int mwaves, int mbc, int mx,
                            const double *ql, const double *qr, double *wave, double *s, double *amdq,
@@ -992,6 +1076,10 @@ static int rpn2_dispatch(int rp, int ixy, int meqn, int mwaves, int mbc, int mx,
         if (!orc_aux1d || orc_maux1d < 2) return -1;
         rpn2_vc_advection(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
         return 0;
+    case RP_PSYSTEM_FWAVE_2D:
+        if (!orc_aux1d || orc_maux1d < 3 || meqn != 3 || mwaves != 2) return -1;
+        rp_fwave_normal(ixy + 1, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq);
+        return 0;
     case RP_SHALLOW_SPHERE_2D:
         if (!orc_aux1d || orc_maux1d < 16 || meqn != 4 || mwaves != 3) return -1;
         rpn2_sphere(ixy, meqn, mwaves, mbc, mx, ql, qr, wave, s, amdq, apdq, par);
@@ -1018,6 +1106,10 @@ static int rpt2_dispatch(int rp, int ixy, int meqn, int mbc, int mx, const doubl
     case RP_VC_ADVECTION_2D:
         if (!orc_aux1d || !orc_auxa1d) return -1;
         rpt2_vc_advection(ixy, imp, meqn, mbc, mx, asdq, bmasdq, bpasdq);
+        return 0;
+    case RP_PSYSTEM_FWAVE_2D:
+        if (!orc_aux1d || !orc_auxb1d || !orc_auxa1d || orc_maux1d < 4) return -1;
+        rpt2_psystem(ixy, imp, meqn, mbc, mx, asdq, bmasdq, bpasdq);
         return 0;
     case RP_SHALLOW_SPHERE_2D:
         if (!orc_aux1d || !orc_auxb1d || !orc_auxa1d) return -1;
@@ -1360,9 +1452,26 @@ int orc_step2(int rp, const double *par, int fwave, int maxm, int meqn, int mwav
 
 /* ------------------------------------------------------------------ step1 */
 /* step1.f:55-139 ; q updated in place, aux(maux, 1-mbc:mx+mbc) */
+static int step1_body(int rp, const double *par, int meqn, int mwaves, int maux, int mbc, int mx,
+                      double *q, const double *aux, double dx, double dt, const int *method,
+                      const int *mthlim, double *cfl_out, int fwave);
 int orc_step1(int rp, const double *par, int meqn, int mwaves, int maux, int mbc, int mx,
               double *q, const double *aux, double dx, double dt, const int *method,
               const int *mthlim, double *cfl_out)
+{
+    return step1_body(rp, par, meqn, mwaves, maux, mbc, mx, q, aux, dx, dt, method, mthlim, cfl_out, 0);
+}
+/* step1fw.f:62-156: the f-wave twin (classic1fw): limiter on the f-waves, correction 0.5*dsign(1,s)*(1-|s|dtdxave)*fwave
+ * (:139-140), final flux differencing over cells 1..mx (:151-154; step1.f runs 1..mx+1, a ghost cell) */
+int orc_step1fw(int rp, const double *par, int meqn, int mwaves, int maux, int mbc, int mx,
+                double *q, const double *aux, double dx, double dt, const int *method,
+                const int *mthlim, double *cfl_out)
+{
+    return step1_body(rp, par, meqn, mwaves, maux, mbc, mx, q, aux, dx, dt, method, mthlim, cfl_out, 1);
+}
+static int step1_body(int rp, const double *par, int meqn, int mwaves, int maux, int mbc, int mx,
+                      double *q, const double *aux, double dx, double dt, const int *method,
+                      const int *mthlim, double *cfl_out, int fwave)
 {
     size_t n = (size_t)(mx + 2 * mbc);
     double *wave = calloc(n * meqn * mwaves, sizeof(double));
@@ -1393,8 +1502,15 @@ int orc_step1(int rp, const double *par, int meqn, int mwaves, int maux, int mbc
         rp1_advection_color(meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq);
         orc_aux1d = NULL;
         break;
+    case RP_ELASTICITY_FWAVE_1D:
+        if (!fwave || maux < 3 || meqn != 2 || mwaves != 2) { rc = -1; break; }
+        orc_aux1d = aux; orc_maux1d = maux;
+        rp_fwave_normal(2, meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq);
+        orc_aux1d = NULL;
+        break;
     default: rc = -1;
     }
+    if (fwave && rp != RP_ELASTICITY_FWAVE_1D) rc = -1;
     if (!rc) {
         for (int i = 1; i <= mx + 1; i++)
             for (int m = 1; m <= meqn; m++)
@@ -1414,10 +1530,14 @@ int orc_step1(int rp, const double *par, int meqn, int mwaves, int maux, int mbc
                     for (int mw = 1; mw <= mwaves; mw++) {
                         double dtdxave = 0.5 * (DT(i - 1) + DT(i));
                         double sa = fabs(S(mw, i));
-                        A2(f, m, i) = A2(f, m, i) +
-                                      0.5 * sa * (1.0 - sa * dtdxave) * W(m, mw, i);
+                        if (fwave)
+                            A2(f, m, i) = A2(f, m, i) +
+                                          0.5 * copysign(1.0, S(mw, i)) * (1.0 - sa * dtdxave) * W(m, mw, i);
+                        else
+                            A2(f, m, i) = A2(f, m, i) +
+                                          0.5 * sa * (1.0 - sa * dtdxave) * W(m, mw, i);
                     }
-            for (int i = 1; i <= mx + 1; i++)
+            for (int i = 1; i <= (fwave ? mx : mx + 1); i++)
                 for (int m = 1; m <= meqn; m++)
                     A2(q, m, i) = A2(q, m, i) - DT(i) * (A2(f, m, i + 1) - A2(f, m, i));
         }
@@ -1611,6 +1731,315 @@ int orc_step3ds(int rp, int maxm, int meqn, int mwaves, int maux, int mbc, int m
         }
     *cfl_out = cfl;
     free(aux1d);
+    work_free(&w);
+    return rc;
+}
+
+/* ======================================================================== 3-D, unsplit (step3.f + flux3.f) */
+/* Transverse solvers of the variable-coefficient acoustics equations in 3-D, restated (THIRD-PARTY
+ * rpt3_vc_acoustics.f / rptt3_vc_acoustics.f, named by test/acoustics/3d/Makefile:3, absent from the reference tree).
+ * Pinned through the reference's golden test/pressure_3D.txt (test_3D_acoustics_heterogeneous, gate 2-norm < 1e-4,
+ * test/test_examples.py:497-514): tests/test_classic3d_unsplit.py.
+ * auxN(ma, i, kk): N = 1,2,3 <-> the row below / at / above the slice in the y-like direction, kk = 1,2,3 <-> below /
+ * at / above in the z-like direction (step3.f:130-142, 253-260, 445-456).  asdq sits in cell i1 = i-2+imp.
+ * The part going down enters the neighbouring row with ITS sound speed and impedance, like the 2-D solver. */
+#define AX3(arr, ma, i, kk) arr[((ma)-1) + (size_t)maux * (IX(i) + (size_t)nrow * ((kk)-1))]
+static void rpt3_vc_acoustics(int ixyz, int icoor, int meqn, int maux, int mbc, int mx, int nrow,
+                              const double *aux1, const double *aux2, const double *aux3, int imp,
+                              const double *asdq, double *bmasdq, double *bpasdq)
+{
+    int iuvw = ixyz + icoor - 1;
+    if (iuvw > 3) iuvw = iuvw - 3;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const int i1 = i - 2 + imp;
+        double zm, zz, zp, cm, cp;
+        if (icoor == 2) {
+            zm = AX3(aux1, 1, i1, 2); zz = AX3(aux2, 1, i1, 2); zp = AX3(aux3, 1, i1, 2);
+            cm = AX3(aux1, 2, i1, 2); cp = AX3(aux3, 2, i1, 2);
+        } else {
+            zm = AX3(aux2, 1, i1, 1); zz = AX3(aux2, 1, i1, 2); zp = AX3(aux2, 1, i1, 3);
+            cm = AX3(aux2, 2, i1, 1); cp = AX3(aux2, 2, i1, 3);
+        }
+        const double a1 = (-A2(asdq, 1, i) + A2(asdq, iuvw + 1, i) * zz) / (zm + zz);
+        const double a2 = (A2(asdq, 1, i) + A2(asdq, iuvw + 1, i) * zz) / (zz + zp);
+        for (int m = 1; m <= meqn; m++) { A2(bmasdq, m, i) = 0.0; A2(bpasdq, m, i) = 0.0; }
+        A2(bmasdq, 1, i) = cm * a1 * zm;
+        A2(bmasdq, iuvw + 1, i) = -cm * a1;
+        A2(bpasdq, 1, i) = cp * a2 * zp;
+        A2(bpasdq, iuvw + 1, i) = cp * a2;
+    }
+}
+/* double-transverse: bsasdq came out of a transverse solve that went down (impt = 1) or up (impt = 2) in the OTHER
+ * transverse direction, so the three rows of the new split lie in that neighbouring row */
+static void rptt3_vc_acoustics(int ixyz, int icoor, int meqn, int maux, int mbc, int mx, int nrow,
+                               const double *aux1, const double *aux2, const double *aux3, int imp, int impt,
+                               const double *bsasdq, double *cmbsasdq, double *cpbsasdq)
+{
+    int iuvw = ixyz + icoor - 1;
+    if (iuvw > 3) iuvw = iuvw - 3;
+    for (int i = 2 - mbc; i <= mx + mbc; i++) {
+        const int i1 = i - 2 + imp;
+        double zm, zz, zp, cm, cp;
+        if (icoor == 2) {             /* new split in the y-like direction, inside the z-like row kk */
+            const int kk = impt == 1 ? 1 : 3;
+            zm = AX3(aux1, 1, i1, kk); zz = AX3(aux2, 1, i1, kk); zp = AX3(aux3, 1, i1, kk);
+            cm = AX3(aux1, 2, i1, kk); cp = AX3(aux3, 2, i1, kk);
+        } else {                      /* new split in the z-like direction, inside the y-like row aux1 / aux3 */
+            const double *a = impt == 1 ? aux1 : aux3;
+            zm = AX3(a, 1, i1, 1); zz = AX3(a, 1, i1, 2); zp = AX3(a, 1, i1, 3);
+            cm = AX3(a, 2, i1, 1); cp = AX3(a, 2, i1, 3);
+        }
+        const double a1 = (-A2(bsasdq, 1, i) + A2(bsasdq, iuvw + 1, i) * zz) / (zm + zz);
+        const double a2 = (A2(bsasdq, 1, i) + A2(bsasdq, iuvw + 1, i) * zz) / (zz + zp);
+        for (int m = 1; m <= meqn; m++) { A2(cmbsasdq, m, i) = 0.0; A2(cpbsasdq, m, i) = 0.0; }
+        A2(cmbsasdq, 1, i) = cm * a1 * zm;
+        A2(cmbsasdq, iuvw + 1, i) = -cm * a1;
+        A2(cpbsasdq, 1, i) = cp * a2 * zp;
+        A2(cpbsasdq, iuvw + 1, i) = cp * a2;
+    }
+}
+
+/* gadd(m, side 1:2, slice -1:1, i), hadd likewise (flux3.f:133-134) */
+#define GA(arr, m, k, j, i) arr[((m)-1) + (size_t)meqn * (((k)-1) + 2 * (((j) + 1) + 3 * (size_t)IX(i)))]
+
+/* flux3.f:168-593, unsplit (method(3) >= 0); the 24 transverse work arrays live in tw[] */
+static int flux3_full(int rp, int ixyz, int meqn, int mwaves, int maux, int mbc, int mx, int nrow,
+                      const int *method, const int *mthlim, work_t *w, double dtdy, double dtdz,
+                      const double *aux1, const double *aux2, const double *aux3, double *gadd, double *hadd,
+                      double **tw, double *cfl1d_out)
+{
+    double *wave = w->wave, *s = w->s, *amdq = w->amdq, *apdq = w->apdq, *cqxx = w->cqxx;
+    double *q1d = w->q1d, *qadd = w->qadd, *fadd = w->fadd, *dtdx1d = w->dtdx1d;
+    double *bmamdq = tw[0], *bmapdq = tw[1], *bpamdq = tw[2], *bpapdq = tw[3];
+    double *cmamdq = tw[4], *cmapdq = tw[5], *cpamdq = tw[6], *cpapdq = tw[7];
+    double *cmamdq2 = tw[8], *cmapdq2 = tw[9], *cpamdq2 = tw[10], *cpapdq2 = tw[11];
+    double *bmcqxxp = tw[12], *bpcqxxp = tw[13], *bmcqxxm = tw[14], *bpcqxxm = tw[15];
+    double *cmcqxxp = tw[16], *cpcqxxp = tw[17], *cmcqxxm = tw[18], *cpcqxxm = tw[19];
+    double *bmcmamdq = tw[20], *bmcmapdq = tw[21], *bpcmamdq = tw[22], *bpcmapdq = tw[23];
+    double *bmcpamdq = tw[24], *bmcpapdq = tw[25], *bpcpamdq = tw[26], *bpcpapdq = tw[27];
+#define DT(i) dtdx1d[IX(i)]
+    int limit = 0;
+    for (int mw = 0; mw < mwaves; mw++)
+        if (mthlim[mw] > 0) limit = 1;
+    for (int i = 1 - mbc; i <= mx + mbc; i++)
+        for (int m = 1; m <= meqn; m++) {
+            A2(qadd, m, i) = 0.0;
+            A2(fadd, m, i) = 0.0;
+            for (int k = 1; k <= 2; k++)
+                for (int j = -1; j <= 1; j++) { GA(gadd, m, k, j, i) = 0.0; GA(hadd, m, k, j, i) = 0.0; }
+        }
+    const int m3 = method[2] / 10, m4 = method[2] - 10 * m3;
+    if (rp != RP_VC_ACOUSTICS_3D) return -1;
+    const double *aux22 = aux2 + (size_t)maux * nrow;      /* aux2(:, :, 2): the slice's own aux */
+    rpn3_vc_acoustics(ixyz, meqn, mwaves, maux, mbc, mx, q1d, q1d, aux22, aux22, wave, s, amdq, apdq);
+    for (int i = 1; i <= mx + 1; i++)
+        for (int m = 1; m <= meqn; m++) A2(qadd, m, i) = A2(qadd, m, i) - DT(i) * A2(apdq, m, i);
+    for (int i = 1; i <= mx + 1; i++)
+        for (int m = 1; m <= meqn; m++) A2(qadd, m, i - 1) = A2(qadd, m, i - 1) - DT(i - 1) * A2(amdq, m, i);
+    double cfl1d = 0.0;
+    for (int i = 1; i <= mx + 1; i++)
+        for (int mw = 1; mw <= mwaves; mw++)
+            cfl1d = dmax(dmax(cfl1d, DT(i) * S(mw, i)), -DT(i - 1) * S(mw, i));
+    *cfl1d_out = cfl1d;
+    if (method[1] != 1) {
+        if (limit) limiter(meqn, mwaves, mbc, mx, wave, s, mthlim);
+        for (int i = 2 - mbc; i <= mx + mbc; i++) {
+            double dtdxave = 0.5 * (DT(i - 1) + DT(i));
+            for (int m = 1; m <= meqn; m++) A2(cqxx, m, i) = 0.0;
+            for (int mw = 1; mw <= mwaves; mw++)
+                for (int m = 1; m <= meqn; m++)
+                    A2(cqxx, m, i) = A2(cqxx, m, i) +
+                                     0.5 * fabs(S(mw, i)) * (1.0 - fabs(S(mw, i)) * dtdxave) * W(m, mw, i);
+            for (int m = 1; m <= meqn; m++) A2(fadd, m, i) = A2(fadd, m, i) + A2(cqxx, m, i);
+        }
+    }
+    if (m3 <= 0) return 0;      /* flux3.f:260: no transverse propagation */
+
+#define RPT3(icoor, imp, in, om, op) rpt3_vc_acoustics(ixyz, icoor, meqn, maux, mbc, mx, nrow, aux1, aux2, aux3, imp, in, om, op)
+#define RPTT3(icoor, imp, impt, in, om, op) \
+    rptt3_vc_acoustics(ixyz, icoor, meqn, maux, mbc, mx, nrow, aux1, aux2, aux3, imp, impt, in, om, op)
+    RPT3(2, 1, amdq, bmamdq, bpamdq);
+    RPT3(2, 2, apdq, bmapdq, bpapdq);
+    RPT3(3, 1, amdq, cmamdq, cpamdq);
+    RPT3(3, 2, apdq, cmapdq, cpapdq);
+    if (m3 == 2) {              /* maux > 0: split cqxx with imp = 1 and imp = 2 (flux3.f:299-321) */
+        RPT3(2, 1, cqxx, bmcqxxm, bpcqxxm);
+        RPT3(2, 2, cqxx, bmcqxxp, bpcqxxp);
+        RPT3(3, 1, cqxx, cmcqxxm, cpcqxxm);
+        RPT3(3, 2, cqxx, cmcqxxp, cpcqxxp);
+    }
+    /* ---- G fluxes (y-like direction), flux3.f:347-452 */
+    if (m4 == 1) {
+        for (int i = 0; i <= mx + 2; i++)
+            for (int m = 1; m <= meqn; m++) {
+                A2(cpapdq2, m, i) = A2(cpapdq, m, i); A2(cpamdq2, m, i) = A2(cpamdq, m, i);
+                A2(cmapdq2, m, i) = A2(cmapdq, m, i); A2(cmamdq2, m, i) = A2(cmamdq, m, i);
+            }
+    } else if (m4 == 2) {
+        for (int i = 0; i <= mx + 2; i++)
+            for (int m = 1; m <= meqn; m++) {
+                A2(cpapdq2, m, i) = A2(cpapdq, m, i) - 3.0 * A2(cpcqxxp, m, i);
+                A2(cpamdq2, m, i) = A2(cpamdq, m, i) + 3.0 * A2(cpcqxxm, m, i);
+                A2(cmapdq2, m, i) = A2(cmapdq, m, i) - 3.0 * A2(cmcqxxp, m, i);
+                A2(cmamdq2, m, i) = A2(cmamdq, m, i) + 3.0 * A2(cmcqxxm, m, i);
+            }
+    }
+    if (m4 > 0) {
+        RPTT3(2, 2, 2, cpapdq2, bmcpapdq, bpcpapdq);
+        RPTT3(2, 1, 2, cpamdq2, bmcpamdq, bpcpamdq);
+        RPTT3(2, 2, 1, cmapdq2, bmcmapdq, bpcmapdq);
+        RPTT3(2, 1, 1, cmamdq2, bmcmamdq, bpcmamdq);
+    }
+    const double sixth = 1.0 / 6.0;
+    for (int i = 1; i <= mx + 1; i++)
+        for (int m = 1; m <= meqn; m++) {
+            GA(gadd, m, 1, 0, i - 1) = GA(gadd, m, 1, 0, i - 1) - 0.5 * DT(i - 1) * A2(bmamdq, m, i);
+            GA(gadd, m, 2, 0, i - 1) = GA(gadd, m, 2, 0, i - 1) - 0.5 * DT(i - 1) * A2(bpamdq, m, i);
+            GA(gadd, m, 1, 0, i) = GA(gadd, m, 1, 0, i) - 0.5 * DT(i) * A2(bmapdq, m, i);
+            GA(gadd, m, 2, 0, i) = GA(gadd, m, 2, 0, i) - 0.5 * DT(i) * A2(bpapdq, m, i);
+            if (m4 > 0) {
+                GA(gadd, m, 2, 0, i) = GA(gadd, m, 2, 0, i) + sixth * DT(i) * dtdz * (A2(bpcpapdq, m, i) - A2(bpcmapdq, m, i));
+                GA(gadd, m, 1, 0, i) = GA(gadd, m, 1, 0, i) + sixth * DT(i) * dtdz * (A2(bmcpapdq, m, i) - A2(bmcmapdq, m, i));
+                GA(gadd, m, 2, 1, i) = GA(gadd, m, 2, 1, i) - sixth * DT(i) * dtdz * A2(bpcpapdq, m, i);
+                GA(gadd, m, 1, 1, i) = GA(gadd, m, 1, 1, i) - sixth * DT(i) * dtdz * A2(bmcpapdq, m, i);
+                GA(gadd, m, 2, -1, i) = GA(gadd, m, 2, -1, i) + sixth * DT(i) * dtdz * A2(bpcmapdq, m, i);
+                GA(gadd, m, 1, -1, i) = GA(gadd, m, 1, -1, i) + sixth * DT(i) * dtdz * A2(bmcmapdq, m, i);
+                GA(gadd, m, 2, 0, i - 1) = GA(gadd, m, 2, 0, i - 1) + sixth * DT(i - 1) * dtdz * (A2(bpcpamdq, m, i) - A2(bpcmamdq, m, i));
+                GA(gadd, m, 1, 0, i - 1) = GA(gadd, m, 1, 0, i - 1) + sixth * DT(i - 1) * dtdz * (A2(bmcpamdq, m, i) - A2(bmcmamdq, m, i));
+                GA(gadd, m, 2, 1, i - 1) = GA(gadd, m, 2, 1, i - 1) - sixth * DT(i - 1) * dtdz * A2(bpcpamdq, m, i);
+                GA(gadd, m, 1, 1, i - 1) = GA(gadd, m, 1, 1, i - 1) - sixth * DT(i - 1) * dtdz * A2(bmcpamdq, m, i);
+                GA(gadd, m, 2, -1, i - 1) = GA(gadd, m, 2, -1, i - 1) + sixth * DT(i - 1) * dtdz * A2(bpcmamdq, m, i);
+                GA(gadd, m, 1, -1, i - 1) = GA(gadd, m, 1, -1, i - 1) + sixth * DT(i - 1) * dtdz * A2(bmcmamdq, m, i);
+            }
+            if (m3 < 2) continue;
+            GA(gadd, m, 2, 0, i) = GA(gadd, m, 2, 0, i) + DT(i) * A2(bpcqxxp, m, i);
+            GA(gadd, m, 1, 0, i) = GA(gadd, m, 1, 0, i) + DT(i) * A2(bmcqxxp, m, i);
+            GA(gadd, m, 2, 0, i - 1) = GA(gadd, m, 2, 0, i - 1) - DT(i - 1) * A2(bpcqxxm, m, i);
+            GA(gadd, m, 1, 0, i - 1) = GA(gadd, m, 1, 0, i - 1) - DT(i - 1) * A2(bmcqxxm, m, i);
+        }
+    /* ---- H fluxes (z-like direction), flux3.f:462-590 */
+    if (m4 == 2)
+        for (int i = 0; i <= mx + 2; i++)
+            for (int m = 1; m <= meqn; m++) {
+                A2(bpapdq, m, i) = A2(bpapdq, m, i) - 3.0 * A2(bpcqxxp, m, i);
+                A2(bpamdq, m, i) = A2(bpamdq, m, i) + 3.0 * A2(bpcqxxm, m, i);
+                A2(bmapdq, m, i) = A2(bmapdq, m, i) - 3.0 * A2(bmcqxxp, m, i);
+                A2(bmamdq, m, i) = A2(bmamdq, m, i) + 3.0 * A2(bmcqxxm, m, i);
+            }
+    if (m4 > 0) {
+        RPTT3(3, 2, 2, bpapdq, bmcpapdq, bpcpapdq);
+        RPTT3(3, 1, 2, bpamdq, bmcpamdq, bpcpamdq);
+        RPTT3(3, 2, 1, bmapdq, bmcmapdq, bpcmapdq);
+        RPTT3(3, 1, 1, bmamdq, bmcmamdq, bpcmamdq);
+    }
+    for (int i = 1; i <= mx + 1; i++)
+        for (int m = 1; m <= meqn; m++) {
+            GA(hadd, m, 1, 0, i - 1) = GA(hadd, m, 1, 0, i - 1) - 0.5 * DT(i - 1) * A2(cmamdq, m, i);
+            GA(hadd, m, 2, 0, i - 1) = GA(hadd, m, 2, 0, i - 1) - 0.5 * DT(i - 1) * A2(cpamdq, m, i);
+            GA(hadd, m, 1, 0, i) = GA(hadd, m, 1, 0, i) - 0.5 * DT(i) * A2(cmapdq, m, i);
+            GA(hadd, m, 2, 0, i) = GA(hadd, m, 2, 0, i) - 0.5 * DT(i) * A2(cpapdq, m, i);
+            if (m4 > 0) {
+                GA(hadd, m, 2, 0, i) = GA(hadd, m, 2, 0, i) + sixth * DT(i) * dtdy * (A2(bpcpapdq, m, i) - A2(bpcmapdq, m, i));
+                GA(hadd, m, 1, 0, i) = GA(hadd, m, 1, 0, i) + sixth * DT(i) * dtdy * (A2(bmcpapdq, m, i) - A2(bmcmapdq, m, i));
+                GA(hadd, m, 2, 1, i) = GA(hadd, m, 2, 1, i) - sixth * DT(i) * dtdy * A2(bpcpapdq, m, i);
+                GA(hadd, m, 1, 1, i) = GA(hadd, m, 1, 1, i) - sixth * DT(i) * dtdy * A2(bmcpapdq, m, i);
+                GA(hadd, m, 2, -1, i) = GA(hadd, m, 2, -1, i) + sixth * DT(i) * dtdy * A2(bpcmapdq, m, i);
+                GA(hadd, m, 1, -1, i) = GA(hadd, m, 1, -1, i) + sixth * DT(i) * dtdy * A2(bmcmapdq, m, i);
+                GA(hadd, m, 2, 0, i - 1) = GA(hadd, m, 2, 0, i - 1) + sixth * DT(i - 1) * dtdy * (A2(bpcpamdq, m, i) - A2(bpcmamdq, m, i));
+                GA(hadd, m, 1, 0, i - 1) = GA(hadd, m, 1, 0, i - 1) + sixth * DT(i - 1) * dtdy * (A2(bmcpamdq, m, i) - A2(bmcmamdq, m, i));
+                GA(hadd, m, 2, 1, i - 1) = GA(hadd, m, 2, 1, i - 1) - sixth * DT(i - 1) * dtdy * A2(bpcpamdq, m, i);
+                GA(hadd, m, 1, 1, i - 1) = GA(hadd, m, 1, 1, i - 1) - sixth * DT(i - 1) * dtdy * A2(bmcpamdq, m, i);
+                GA(hadd, m, 2, -1, i - 1) = GA(hadd, m, 2, -1, i - 1) + sixth * DT(i - 1) * dtdy * A2(bpcmamdq, m, i);
+                GA(hadd, m, 1, -1, i - 1) = GA(hadd, m, 1, -1, i - 1) + sixth * DT(i - 1) * dtdy * A2(bmcmamdq, m, i);
+            }
+            if (m3 < 2) continue;
+            GA(hadd, m, 2, 0, i) = GA(hadd, m, 2, 0, i) + DT(i) * A2(cpcqxxp, m, i);
+            GA(hadd, m, 1, 0, i) = GA(hadd, m, 1, 0, i) + DT(i) * A2(cmcqxxp, m, i);
+            GA(hadd, m, 2, 0, i - 1) = GA(hadd, m, 2, 0, i - 1) - DT(i - 1) * A2(cpcqxxm, m, i);
+            GA(hadd, m, 1, 0, i - 1) = GA(hadd, m, 1, 0, i - 1) - DT(i - 1) * A2(cmcqxxm, m, i);
+        }
+    return 0;
+#undef DT
+#undef RPT3
+#undef RPTT3
+}
+
+/* step3.f:96-592 (unsplit; no capacity function: the reference apps in 3-D have none and the product rejects it) */
+int orc_step3(int rp, int maxm, int meqn, int mwaves, int maux, int mbc, int mx, int my, int mz,
+              const double *qold, double *qnew, const double *aux, double dx, double dy, double dz, double dt,
+              const int *method, const int *mthlim, double *cfl_out)
+{
+    if (method[5] != 0 || maux <= 0) return -3;
+    work_t w;
+    work_alloc(&w, maxm, mbc, meqn, mwaves);
+    const int nrow = maxm + 2 * mbc;
+    double *q1d = w.q1d, *qadd = w.qadd, *fadd = w.fadd, *dtdx1d = w.dtdx1d;
+    double *aux1 = calloc((size_t)maux * nrow * 3, sizeof(double)), *aux2 = calloc((size_t)maux * nrow * 3, sizeof(double));
+    double *aux3 = calloc((size_t)maux * nrow * 3, sizeof(double));
+    double *gadd = calloc((size_t)meqn * 6 * nrow, sizeof(double)), *hadd = calloc((size_t)meqn * 6 * nrow, sizeof(double));
+    double *tw[28];
+    for (int k = 0; k < 28; k++) tw[k] = calloc((size_t)meqn * nrow, sizeof(double));
+    double cfl = 0.0, cfl1d = 0.0;
+    const double dtd[3] = {dt / dx, dt / dy, dt / dz};
+    const int n[3] = {mx, my, mz};
+    int rc = 0;
+    for (int idir = 1; idir <= 3 && !rc; idir++) {
+        const int d = idir - 1, e = (d + 1) % 3, f = (d + 2) % 3;      /* sweep, y-like, z-like directions */
+        const int nd = n[d];
+        /* loop nest of the Fortran: x: k outer, j inner; y: k outer, i inner; z: j outer, i inner */
+        const int outer = idir == 3 ? 1 : 2, inner = idir == 1 ? 1 : 0;
+        for (int i = 1 - mbc; i <= maxm + mbc; i++) dtdx1d[IX(i)] = dtd[d];
+        for (int a = 0; a <= n[outer] + 1 && !rc; a++)
+            for (int b = 0; b <= n[inner] + 1 && !rc; b++) {
+                int c[3];
+                c[outer] = a;
+                c[inner] = b;
+                for (int t = 1 - mbc; t <= nd + mbc; t++) {
+                    c[d] = t;
+                    for (int m = 1; m <= meqn; m++) A2(q1d, m, t) = Q4(qold, m, c[0], c[1], c[2]);
+                    for (int oe = -1; oe <= 1; oe++)
+                        for (int of = -1; of <= 1; of++) {
+                            int cc[3] = {c[0], c[1], c[2]};
+                            cc[e] += oe;
+                            cc[f] += of;
+                            double *dst = oe < 0 ? aux1 : (oe == 0 ? aux2 : aux3);
+                            for (int ma = 1; ma <= maux; ma++)
+                                dst[(ma - 1) + (size_t)maux * (IX(t) + (size_t)nrow * (of + 1))] = AUX4(ma, cc[0], cc[1], cc[2]);
+                        }
+                }
+                rc = flux3_full(rp, idir, meqn, mwaves, maux, mbc, nd, nrow, method, mthlim, &w, dtd[e], dtd[f], aux1, aux2,
+                                aux3, gadd, hadd, tw, &cfl1d);
+                cfl = dmax(cfl, cfl1d);
+                const double dty = dtd[e], dtz = dtd[f];
+                for (int t = 1; t <= nd; t++)
+                    for (int m = 1; m <= meqn; m++) {
+                        c[d] = t;
+#define QN(oe, of) (*qn_at(qnew, meqn, mbc, mx, my, c, e, f, oe, of, m))
+#define G_(k, j) GA(gadd, m, k, j, t)
+#define H_(k, j) GA(hadd, m, k, j, t)
+                        double *p;
+                        int cc[3];
+#define AT(oe, of) (cc[0] = c[0], cc[1] = c[1], cc[2] = c[2], cc[e] += (oe), cc[f] += (of), p = &Q4(qnew, m, cc[0], cc[1], cc[2]))
+                        AT(0, 0);   *p = *p + A2(qadd, m, t) - dtd[d] * (A2(fadd, m, t + 1) - A2(fadd, m, t)) -
+                                         dty * (G_(2, 0) - G_(1, 0)) - dtz * (H_(2, 0) - H_(1, 0));
+                        AT(-1, 0);  *p = *p - dty * G_(1, 0) - dtz * (H_(2, -1) - H_(1, -1));
+                        AT(-1, -1); *p = *p - dty * G_(1, -1) - dtz * H_(1, -1);
+                        AT(0, -1);  *p = *p - dty * (G_(2, -1) - G_(1, -1)) - dtz * H_(1, 0);
+                        AT(1, -1);  *p = *p + dty * G_(2, -1) - dtz * H_(1, 1);
+                        AT(1, 0);   *p = *p + dty * G_(2, 0) - dtz * (H_(2, 1) - H_(1, 1));
+                        AT(1, 1);   *p = *p + dty * G_(2, 1) + dtz * H_(2, 1);
+                        AT(0, 1);   *p = *p - dty * (G_(2, 1) - G_(1, 1)) + dtz * H_(2, 0);
+                        AT(-1, 1);  *p = *p - dty * G_(1, 1) + dtz * H_(2, -1);
+#undef AT
+#undef G_
+#undef H_
+#undef QN
+                    }
+            }
+    }
+    *cfl_out = cfl;
+    free(aux1); free(aux2); free(aux3); free(gadd); free(hadd);
+    for (int k = 0; k < 28; k++) free(tw[k]);
     work_free(&w);
     return rc;
 }

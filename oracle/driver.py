@@ -155,7 +155,7 @@ def step_hyperbolic(p, backend):
     if p.ndim == 1:
         mx = p.q.shape[1]
         _, cfl = backend.step1(p.rp, p.rp_params, mbc, mx, p.qbc, p.auxbc, p.d[0], p.dt,
-                               p.method, p.mthlim)
+                               p.method, p.mthlim, fwave=p.fwave)
     elif p.ndim == 3:                                       # clawpack.py:650-699 (dim_split only)
         mx, my, mz = p.q.shape[1:]
         maxm = max(mx, my, mz)

@@ -34,6 +34,8 @@ RP_VC_ACOUSTICS_2D = 14
 RP_VC_ADVECTION_2D = 15
 RP_EULER5_2D = 11
 RP_SHALLOW_SPHERE_2D = 16
+RP_ELASTICITY_FWAVE_1D = 7
+RP_PSYSTEM_FWAVE_2D = 17
 RP_VC_ACOUSTICS_3D = 20
 
 _dp = C.POINTER(C.c_double)
@@ -73,6 +75,8 @@ class COracle:
         L.orc_step1.restype = C.c_int
         L.orc_step1.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
                                 C.c_double, C.c_double, _ip, _ip, _dp]
+        L.orc_step1fw.restype = C.c_int
+        L.orc_step1fw.argtypes = L.orc_step1.argtypes
         L.orc_rpn2.restype = C.c_int
         L.orc_rpn2.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
                                _dp, _dp, _dp]
@@ -90,6 +94,8 @@ class COracle:
                                       C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp]
         L.orc_weno5.restype = None
         L.orc_weno5.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.orc_sharp_set_mthlim.restype = None
+        L.orc_sharp_set_mthlim.argtypes = [_ip, C.c_int]
         L.orc_sphere_qcor.restype = None
         L.orc_sphere_qcor.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp]
         L.orc_set_qcor.restype = None
@@ -155,7 +161,8 @@ class COracle:
             raise RuntimeError("oracle: unknown Riemann solver id %d" % rp)
         return qnew, cfl.value
 
-    def step1(self, rp, par, mbc, mx, q, aux, dx, dt, method, mthlim):
+    def step1(self, rp, par, mbc, mx, q, aux, dx, dt, method, mthlim, fwave=False):
+        """classic1.step1 (step1.f) or, fwave=True, classic1fw.step1 (step1fw.f)"""
         meqn = q.shape[0]
         par = np.ascontiguousarray(par, dtype=np.float64)
         method = np.ascontiguousarray(method, dtype=np.int32)
@@ -164,13 +171,18 @@ class COracle:
         auxp = _d(aux) if (aux is not None and maux > 0) else _d(np.zeros(1))
         cfl = C.c_double(0.0)
         assert q.flags.f_contiguous
-        rc = self.lib.orc_step1(rp, _d(par), meqn, len(mthlim), maux, mbc, mx, _d(q), auxp, dx, dt,
-                                _i(method), _i(mthlim), C.byref(cfl))
+        fn = self.lib.orc_step1fw if fwave else self.lib.orc_step1
+        rc = fn(rp, _d(par), meqn, len(mthlim), maux, mbc, mx, _d(q), auxp, dx, dt, _i(method), _i(mthlim), C.byref(cfl))
         if rc:
             raise RuntimeError("oracle: unknown Riemann solver id %d" % rp)
         return q, cfl.value
 
     # -- SharpClaw (sharpclaw_oracle.c) ------------------------------------------------
+    def set_sharp_mthlim(self, mthlim):
+        """clawparams.mthlim (sharpclaw.py:268): used by lim_type=1 (tvd2), indexed by component"""
+        m = np.ascontiguousarray(mthlim, dtype=np.int32)
+        self.lib.orc_sharp_set_mthlim(_i(m), len(m))
+
     def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt):
         """sharpclaw2.flux2(q,aux,dt,t,mbc,maxm,mx,my) -> (dq,cfl)  (sharpclaw.py:558)"""
         meqn = q.shape[0]
@@ -357,13 +369,13 @@ class RefSharp2DEuler:
     def available():
         return os.path.exists(os.path.join(_HERE, "_ref", "libref_sharpclaw2d_euler.so"))
 
-    def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt):
+    def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt, mthlim=None):
         assert rp == RP_EULER5_2D and mcapa == 0
         self.cparam.gamma, self.cparam.gamma1 = float(par[0]), float(par[1])
         meqn = q.shape[0]
         maxnx = max(mx, my) + 2 * mbc                      # sharpclaw.py:280
         dxs = np.array([dx, dy])
-        mth = np.array([1] * mwaves, dtype=np.int32)
+        mth = np.array(mthlim if mthlim is not None else [1] * mwaves, dtype=np.int32)
         self.lib.sc_setup(C.c_int(2), C.c_int(meqn), C.c_int(mwaves), C.c_int(mbc), C.c_int(maxnx),
                           C.c_int(lim_type), C.c_int(5), C.c_int(0), C.c_int(0), _d(dxs), _i(mth))
         dq = np.zeros(q.shape, order="F")

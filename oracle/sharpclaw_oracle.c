@@ -6,6 +6,7 @@
  *   flux1                     src/fortran/2d/sharpclaw/flux1.f90:59-188 (1-D twin 1d/sharpclaw/flux1.f90)
  *   weno5 (PyWENO-generated)  src/fortran/1d/sharpclaw/weno.f90:36-100   lim_type=2, char_decomp=0
  *   weno5 (legacy)            src/fortran/1d/sharpclaw/reconstruct.f90:120-185   lim_type=3
+ *   tvd2                      src/fortran/1d/sharpclaw/reconstruct.f90:568-625   lim_type=1, char_decomp=0
  * Only char_decomp=0, tfluct_solver=.false. (the configurations the reference's tests use).
  *
  * The PyWENO source writes its constants WITHOUT a d0 exponent (+3.33333333333333, +0.1, 1.0e-36):
@@ -111,6 +112,50 @@ static void weno5_legacy(const double *q, double *ql, double *qr, int meqn, int 
     free(dq1m);
 }
 
+/* reconstruct.f90:568-625 (tvd2): second-order TVD reconstruction, component-wise; mthlim is indexed by COMPONENT
+ * (select case(mthlim(m)), :594).  Two things a maintainer should know about the reference routine:
+ *  * `dqm = dqp` (:590) runs before dqp has ever been assigned: at the first cell of every component the Fortran
+ *    uses an UNINITIALISED value (for m > 1 the last dqp of the previous component; for m = 1 whatever the stack
+ *    holds).  That only reaches ql/qr of ghost cell 0 and through it the first interior cell of each slice.  Here
+ *    the first cell gets the intended dqm = q(i) - q(i-1); the reference-generated golden is therefore compared
+ *    away from the first interior row / column (tests/test_ref_goldens.py).
+ *  * on locally constant data r = 0/0.  gfortran's MAX/MIN (the reference's compiler) return the non-NaN operand,
+ *    so qlimitr is finite and ql = qr = q; flang's propagate the NaN (oracle/_ref built here returns NaN on a
+ *    constant patch).  fmax/fmin below = the gfortran behaviour, which is also what v_max/min_f64 do on the GPU.
+ * The hard-wired mbc = 2 of the routine means the loop runs over slice indices 3 .. n-2. */
+static int orc_tvd_mthlim[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+void orc_sharp_set_mthlim(const int *mthlim, int n)
+{
+    for (int k = 0; k < 16; k++) orc_tvd_mthlim[k] = (k < n) ? mthlim[k] : 1;
+}
+static void tvd2(const double *q, double *ql, double *qr, int meqn, int n)
+{
+    for (int m = 0; m < meqn; m++) {
+        double dqp = Q(m, 3) - Q(m, 2);
+        for (int i = 3; i <= n - 2; i++) {
+            const double dqm = dqp;
+            dqp = Q(m, i + 1) - Q(m, i);
+            const double r = dqp / dqm;
+            double qlimitr = 0.0;
+            switch (orc_tvd_mthlim[m]) {
+            case 1: qlimitr = fmax(0.0, fmin(1.0, r)); break;
+            case 2: qlimitr = fmax(fmax(0.0, fmin(1.0, 2.0 * r)), fmin(2.0, r)); break;
+            case 3: qlimitr = (r + fabs(r)) / (1.0 + fabs(r)); break;
+            case 4: { const double c = (1.0 + r) / 2.0; qlimitr = fmax(0.0, fmin(fmin(c, 2.0), 2.0 * r)); break; }
+            case 5: {
+                const double beta = 2.0, xgamma = 2.0, alpha = 1.0 / 3.0;
+                const double pp = (2.0 + r) / 3.0;
+                const double amax = fmax(fmax(-alpha * r, 0.0), fmin(fmin(beta * r, pp), xgamma));
+                qlimitr = fmax(0.0, fmin(pp, amax));
+                break;
+            }
+            }
+            QR(m, i) = Q(m, i) + 0.5 * qlimitr * dqm;
+            QL(m, i) = Q(m, i) - 0.5 * qlimitr * dqm;
+        }
+    }
+}
+
 /* flux1.f90:59-188 on one slice.  q1d (meqn, 1-mbc:mx+mbc); dq1d same extent, returned. */
 static int flux1(int ndim, int rp, const double *par, int lim_type, int ixy, int meqn, int mwaves, int mbc,
                  int mx, const double *q1d, double *dq1d, const double *dtdx, double *cfl_out, double *work)
@@ -122,7 +167,9 @@ static int flux1(int ndim, int rp, const double *par, int lim_type, int ixy, int
     memset(work, 0, sizeof(double) * ((size_t)meqn * n * 6 + (size_t)meqn * mwaves * n + (size_t)mwaves * n));
     const double *q = q1d;
     /* the Fortran indexes the slice 1..maxnx+2mbc inside weno: i_weno = i_cell + mbc */
-    if (lim_type == 2)
+    if (lim_type == 1)
+        tvd2(q, ql, qr, meqn, n);
+    else if (lim_type == 2)
         weno5_pyweno(q, ql, qr, meqn, n, 3, n - 2);     /* every index whose 5-point stencil is in range */
     else if (lim_type == 3)
         weno5_legacy(q, ql, qr, meqn, n, mbc);

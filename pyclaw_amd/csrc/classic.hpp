@@ -68,6 +68,8 @@ template <class RP> __host__ __device__ constexpr int naux_t() {
     if constexpr (RP::NAUX > 0) return RP::NAUX_T;
     else return 0;
 }
+template <class RP, class = void> struct IsFwave : std::false_type {};
+template <class RP> struct IsFwave<RP, std::void_t<decltype(RP::IS_FWAVE)>> : std::bool_constant<RP::IS_FWAVE> {};
 template <class RP, class = void> struct HasQcor : std::false_type {};
 template <class RP> struct HasQcor<RP, std::void_t<decltype(RP::HAS_QCOR)>> : std::bool_constant<RP::HAS_QCOR> {};
 template <class RP> __host__ __device__ constexpr bool has_qcor() { return HasQcor<RP>::value; }
@@ -240,12 +242,12 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
 #pragma unroll
         for (int mw = 0; mw < MWAVES; mw++) {
             const double sa = fabs(s[mw]);
+            // flux2fw.f:151-152 / step1fw.f:139-140: dsign(1,s) in place of |s| when wave[][] holds f-waves
+            const double mag = FWAVE ? copysign(1.0, s[mw]) : sa;
             if (DIM1 || F3)
-                coef[mw] = 0.5 * sa * (1.0 - sa * dtdxave);
-            else if (FWAVE)
-                coef[mw] = copysign(1.0, s[mw]) * (1.0 - sa * dtdxave);
+                coef[mw] = 0.5 * mag * (1.0 - sa * dtdxave);
             else
-                coef[mw] = sa * (1.0 - sa * dtdxave);
+                coef[mw] = mag * (1.0 - sa * dtdxave);
         }
 #pragma unroll
         for (int m = 0; m < MEQN; m++) {

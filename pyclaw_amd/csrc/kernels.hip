@@ -42,11 +42,17 @@ template <class RP, int IXY, bool DIM1, bool TRANS = false> int launch(const Swe
         if (nblocks == 0) return PCL_OK;
     }
     const dim3 grid(nblocks);
+    constexpr bool FW = IsFwave<RP>::value;       // f-wave solvers run the flux2fw.f / step1fw.f form of the kernel
+    if ((l.fwave != 0) != FW) {
+        err = FW ? "this Riemann solver returns f-waves: set solver.fwave = True (classic1fw / classic2fw)"
+                 : "solver.fwave = True needs an f-wave Riemann solver (elasticity_fwave_1d, psystem_fwave_2d)";
+        return PCL_EINVAL;
+    }
     if (a.mcapa > 0)
-        hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, false, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
+        hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, FW, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
                            ntiles_across, ntiles_along);
     else
-        hipLaunchKernelGGL((sweep_kernel<RP, IXY, false, false, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
+        hipLaunchKernelGGL((sweep_kernel<RP, IXY, false, FW, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
                            ntiles_across, ntiles_along);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep launch", e);
@@ -56,7 +62,6 @@ template <class RP, int IXY, bool DIM1, bool TRANS = false> int launch(const Swe
 
 // one directional sweep qin -> qout; ids 1 = x (or the 1-D step), 2 = y
 int launch_sweep(const SweepLaunch &l, std::string &err) {
-    if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
     const int rp = l.rp;
     if (l.ndim == 1) {
         if (rp == PCL_RP_ADVECTION_1D) return launch<Advection1D, 1, true>(l, err);
@@ -65,6 +70,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_EULER_1D) return launch<Euler1D, 1, true>(l, err);
         if (rp == PCL_RP_SHALLOW_1D) return launch<Shallow1D, 1, true>(l, err);
         if (rp == PCL_RP_ADVECTION_COLOR_1D) return launch<AdvectionColor1D, 1, true>(l, err);
+        if (rp == PCL_RP_ELASTICITY_FWAVE_1D) return launch<Elasticity1D, 1, true>(l, err);
         err = "Riemann solver id is not a 1-D solver";
         return PCL_EINVAL;
     }
@@ -75,6 +81,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 1, false>(l, err);
         if (rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 1, false>(l, err);
         if (rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 1, false>(l, err);
+        if (rp == PCL_RP_PSYSTEM_FWAVE_2D) return launch<PSystem2D, 1, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false>(l, err);
     } else {
         if (rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false>(l, err);
@@ -83,6 +90,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 2, false>(l, err);
         if (rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 2, false>(l, err);
         if (rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 2, false>(l, err);
+        if (rp == PCL_RP_PSYSTEM_FWAVE_2D) return launch<PSystem2D, 2, false>(l, err);
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -92,7 +100,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
 // 3-D dimension-split sweep along direction l.ids (classic.hpp: sweep3_kernel)
 int launch_sweep3(const SweepLaunch &l, std::string &err) {
     const SweepArgs &a = l.a;
-    if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
+    if (l.fwave) { err = "fwave: no 3-D f-wave Riemann solver is built in"; return PCL_EINVAL; }
     if (l.rp != PCL_RP_VC_ACOUSTICS_3D) { err = "Riemann solver id is not a 3-D solver"; return PCL_EINVAL; }
     if (a.mcapa > 0) { err = "3-D sweeps: capacity function not implemented"; return PCL_EINVAL; }
     const int n_ac = l.ids == 1 ? a.n_ac : a.n_ac + (LINE - a.mbc);  // y, z: columns counted from the line boundary
@@ -125,7 +133,6 @@ bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]) {
 
 // unsplit (step2.f): per-slice pieces of one direction into the scratch planes
 int launch_slices(const SweepLaunch &l, std::string &err) {
-    if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
     if (l.ndim != 2) { err = "step2 is 2-D"; return PCL_EINVAL; }
     if (l.ids == 1) {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false, true>(l, err);
@@ -134,6 +141,7 @@ int launch_slices(const SweepLaunch &l, std::string &err) {
         if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 1, false, true>(l, err);
+        if (l.rp == PCL_RP_PSYSTEM_FWAVE_2D) return launch<PSystem2D, 1, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false, true>(l, err);
     } else {
         if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false, true>(l, err);
@@ -142,6 +150,7 @@ int launch_slices(const SweepLaunch &l, std::string &err) {
         if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 2, false, true>(l, err);
+        if (l.rp == PCL_RP_PSYSTEM_FWAVE_2D) return launch<PSystem2D, 2, false, true>(l, err);
         if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false, true>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
@@ -155,12 +164,12 @@ template <class RP, int UX, int UY> int launch_unsplit_u(const SweepLaunch &l, c
     if (l.ids == 1) {
         const int nstrips = (a.mx + STRIP - 1) / STRIP;
         const int ntr = (a.my + (UX - 2) - 1) / (UX - 2);
-        hipLaunchKernelGGL((unsplit_x_kernel<RP, false, UX>), dim3((unsigned)nstrips * ntr), dim3(UX * WAVE), 0,
+        hipLaunchKernelGGL((unsplit_x_kernel<RP, IsFwave<RP>::value, UX>), dim3((unsigned)nstrips * ntr), dim3(UX * WAVE), 0,
                            l.stream, a, nstrips);
     } else {
         const int nti = (a.mx + (UY - 2) - 1) / (UY - 2);
         const int ntj = (a.my + STRIP - 1) / STRIP;
-        hipLaunchKernelGGL((unsplit_y_kernel<RP, false, UY>), dim3((unsigned)nti * ntj), dim3(UY * WAVE), 0,
+        hipLaunchKernelGGL((unsplit_y_kernel<RP, IsFwave<RP>::value, UY>), dim3((unsigned)nti * ntj), dim3(UY * WAVE), 0,
                            l.stream, a, nti, qx);
     }
     hipError_t e = hipGetLastError();
@@ -178,7 +187,11 @@ template <class RP> int launch_unsplit_t(const SweepLaunch &l, const double *qx,
 }  // namespace
 
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
-    if (l.fwave) { err = "fwave: no f-wave Riemann solver is built in yet"; return PCL_EINVAL; }
+    if ((l.fwave != 0) != (l.rp == PCL_RP_PSYSTEM_FWAVE_2D)) {
+        err = "solver.fwave must be True for an f-wave Riemann solver and only for one";
+        return PCL_EINVAL;
+    }
+    if (l.rp == PCL_RP_PSYSTEM_FWAVE_2D) return launch_unsplit_t<PSystem2D>(l, qx, err);
     if (l.rp == PCL_RP_ACOUSTICS_2D) return launch_unsplit_t<Acoustics2D>(l, qx, err);
     if (l.rp == PCL_RP_ADVECTION_2D) return launch_unsplit_t<Advection2D>(l, qx, err);
     if (l.rp == PCL_RP_SHALLOW_2D) return launch_unsplit_t<Shallow2D>(l, qx, err);
@@ -214,9 +227,10 @@ template <class RP, int IXY> int launch_sharp_t(const SweepLaunch &l, std::strin
 #define PCL_SHARP_LAUNCH(CAPA_, LIM_)                                                                  \
     hipLaunchKernelGGL((sharp_kernel<RP, IXY, CAPA_, LIM_>), grid, dim3(256), 0, l.stream, a, ntiles_across, \
                        ntiles_along)
-    if (l.lim_type == 2) { if (capa) PCL_SHARP_LAUNCH(true, 2); else PCL_SHARP_LAUNCH(false, 2); }
+    if (l.lim_type == 1) { if (capa) PCL_SHARP_LAUNCH(true, 1); else PCL_SHARP_LAUNCH(false, 1); }
+    else if (l.lim_type == 2) { if (capa) PCL_SHARP_LAUNCH(true, 2); else PCL_SHARP_LAUNCH(false, 2); }
     else if (l.lim_type == 3) { if (capa) PCL_SHARP_LAUNCH(true, 3); else PCL_SHARP_LAUNCH(false, 3); }
-    else { err = "SharpClaw: lim_type must be 2 (WENO5) or 3 (legacy WENO5)"; return PCL_EINVAL; }
+    else { err = "SharpClaw: lim_type must be 1 (tvd2), 2 (WENO5) or 3 (legacy WENO5)"; return PCL_EINVAL; }
 #undef PCL_SHARP_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "sharp launch", e);

@@ -553,8 +553,10 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->mbc != 3)
         return fail(PCL_EINVAL, "SharpClaw kernels implement weno_order 5: mbc == 3");
     if (cfg->kind != PCL_KIND_CLASSIC && cfg->kind != PCL_KIND_SHARPCLAW) return fail(PCL_EINVAL, "unknown solver kind");
-    if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->lim_type != 2 && cfg->lim_type != 3)
-        return fail(PCL_EINVAL, "SharpClaw: lim_type must be 2 (WENO5) or 3 (legacy WENO5)");
+    if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->lim_type != 1 && cfg->lim_type != 2 && cfg->lim_type != 3)
+        return fail(PCL_EINVAL, "SharpClaw: lim_type must be 1 (tvd2), 2 (WENO5) or 3 (legacy WENO5)");
+    if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->lim_type == 1 && cfg->meqn > PCL_MAX_WAVES)
+        return fail(PCL_EINVAL, "SharpClaw tvd2: mthlim is indexed by component, meqn <= PCL_MAX_WAVES");
     if (cfg->mwaves < 1 || cfg->mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
     if (cfg->math != PCL_MATH_EXACT && cfg->math != PCL_MATH_FAST) return fail(PCL_EINVAL, "unknown math mode");
     int want_meqn = 0, want_mwaves = 0, want_ndim = 0;
@@ -565,6 +567,8 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     case PCL_RP_EULER_1D: want_meqn = 3; want_mwaves = 3; want_ndim = 1; break;
     case PCL_RP_SHALLOW_1D: want_meqn = 2; want_mwaves = 2; want_ndim = 1; break;
     case PCL_RP_ADVECTION_COLOR_1D: want_meqn = 1; want_mwaves = 1; want_ndim = 1; break;
+    case PCL_RP_ELASTICITY_FWAVE_1D: want_meqn = 2; want_mwaves = 2; want_ndim = 1; break;
+    case PCL_RP_PSYSTEM_FWAVE_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
     case PCL_RP_ADVECTION_2D: want_meqn = 1; want_mwaves = 1; want_ndim = 2; break;
     case PCL_RP_SHALLOW_2D: want_meqn = 3; want_mwaves = 3; want_ndim = 2; break;
     case PCL_RP_VC_ACOUSTICS_2D: want_meqn = 3; want_mwaves = 2; want_ndim = 2; break;
@@ -584,6 +588,15 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
         return fail(PCL_EINVAL, "rp1_advection_color needs aux(1) = edge velocity");
     if (cfg->rp == PCL_RP_VC_ACOUSTICS_2D || cfg->rp == PCL_RP_VC_ADVECTION_2D) {
         if (cfg->maux < 2) return fail(PCL_EINVAL, "this Riemann solver needs two aux components (impedance/sound speed or the edge velocities)");
+    }
+    if (cfg->rp == PCL_RP_ELASTICITY_FWAVE_1D || cfg->rp == PCL_RP_PSYSTEM_FWAVE_2D) {
+        if (!cfg->fwave) return fail(PCL_EINVAL, "this Riemann solver returns f-waves: cfg.fwave must be 1 (classic1fw / classic2fw)");
+        if (cfg->maux < 3) return fail(PCL_EINVAL, "f-wave elasticity solvers need aux(1)=rho, aux(2)=K, aux(3)=stress-law flag");
+        if (cfg->rp == PCL_RP_PSYSTEM_FWAVE_2D && cfg->method[2] > 0 && cfg->maux < 4)
+            return fail(PCL_EINVAL, "rpt2_psystem reads aux(4) = strain of the neighbouring rows (the app's b4step fills it)");
+        if (cfg->kind == PCL_KIND_SHARPCLAW) return fail(PCL_EINVAL, "f-wave solvers are wired for the classic solvers only");
+    } else if (cfg->fwave) {
+        return fail(PCL_EINVAL, "cfg.fwave = 1 needs an f-wave Riemann solver (PCL_RP_ELASTICITY_FWAVE_1D, PCL_RP_PSYSTEM_FWAVE_2D)");
     }
     if (cfg->rp == PCL_RP_SHALLOW_SPHERE_2D) {
         if (cfg->maux < 16) return fail(PCL_EINVAL, "rpn2_shallow_sphere needs the 16 aux components of setaux.f (kappa, edge normals/tangents, radial vector)");
@@ -1224,6 +1237,13 @@ int pcl_step1(int rp, const double *rp_params, int meqn, int mwaves, int maux, i
                       method, mthlim, cfl, 1, false);
 }
 
+int pcl_step1fw(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx,
+                double *q, const double *aux, double dx, double dt, const int *method,
+                const int *mthlim, double *cfl) {
+    return host_sweep(1, rp, rp_params, 1, meqn, mwaves, maux, mbc, mx, 1, q, q, aux, dx, 1.0, dt,
+                      method, mthlim, cfl, 1, false);
+}
+
 int pcl_step2ds(int rp, const double *rp_params, int fwave, int meqn, int mwaves, int maux, int mbc,
                 int mx, int my, const double *qold, double *qnew, const double *aux, double dx,
                 double dy, double dt, const int *method, const int *mthlim, double *cfl, int ids) {
@@ -1265,6 +1285,15 @@ int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux,
     return rc;
 }
 
+// clawparams.mthlim of the F90 module state (sharpclaw.py:268): only lim_type = 1 (tvd2) reads it
+static int g_sharp_mthlim[PCL_MAX_WAVES] = {1, 1, 1, 1, 1, 1, 1, 1};
+
+int pcl_sharp_module_mthlim(const int *mthlim, int n) {
+    if (!mthlim || n < 0 || n > PCL_MAX_WAVES) return fail(PCL_EINVAL, "pcl_sharp_module_mthlim: 0 <= n <= PCL_MAX_WAVES");
+    for (int k = 0; k < PCL_MAX_WAVES; k++) g_sharp_mthlim[k] = k < n ? mthlim[k] : 1;
+    return PCL_OK;
+}
+
 static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux,
                       int mcapa, int mbc, int mx, int my, const double *q, double *dq, const double *aux,
                       double dx, double dy, double dt, double *cfl) {
@@ -1273,6 +1302,7 @@ static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, i
     memset(&c, 0, sizeof(c));
     c.ndim = ndim; c.n[0] = mx; c.n[1] = my; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves; c.maux = maux;
     c.method[1] = 2; c.method[5] = mcapa; c.method[6] = maux;
+    for (int k = 0; k < PCL_MAX_WAVES; k++) c.mthlim[k] = g_sharp_mthlim[k];
     c.rp = rp;
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
     c.d[0] = dx; c.d[1] = dy; c.kind = PCL_KIND_SHARPCLAW; c.lim_type = lim_type; c.math = PCL_MATH_EXACT;

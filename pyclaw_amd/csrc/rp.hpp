@@ -710,6 +710,75 @@ struct Shallow2D {
 };
 
 
+
+// ------------------------------------------------------------------------------------
+// f-wave solvers (FWAVE kernels: flux2fw.f / step1fw.f): nonlinear elasticity in 1-D (third-party
+// rp1_nonlinear_elasticity_fwave.f, apps/elasticity/1d/stegoton) and the p-system in 2-D (third-party rpn2_psystem.f /
+// rpt2_psystem.f, test/psystem), restated; same operation order as oracle/classic_oracle.c: rp_fwave_normal /
+// rpt2_psystem.  aux(1) = rho, aux(2) = K, aux(3) = 1: sigma = K eps, else sigma = exp(K eps) - 1; the p-system's
+// transverse solver also reads aux(4) = eps of the neighbouring rows.  wave[][] holds F-WAVES.
+// (exp() is the device library's: the exponential law agrees with the CPU oracle to an ulp, not bit for bit.)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double ps_sigma(double eps, double K, double lin) { return lin == 1.0 ? K * eps : exp(K * eps) - 1.0; }
+__device__ __forceinline__ double ps_sigmap(double eps, double K, double lin) { return lin == 1.0 ? K : K * exp(K * eps); }
+
+template <int NEQ> struct FwaveElastic {
+    static constexpr int MEQN = NEQ, MWAVES = 2, NAUX = 3, NAUX_T = 4;
+    static constexpr bool IS_FWAVE = true;
+    template <int IXY> __host__ __device__ static constexpr int aux_index(int k) { return k; }
+    template <int IXY> __host__ __device__ static constexpr int auxt_index(int k) { return k; }
+    struct Cell { double q[NEQ]; double rho, un, sig, c, z; };
+    template <int IXY> __device__ static constexpr int mu_of() { return NEQ == 2 ? 1 : IXY; }
+    template <int IXY> __device__ static constexpr bool nz(int /*mw*/, int m) { return m == 0 || m == mu_of<IXY>(); }
+    template <int IXY>
+    __device__ static __forceinline__ Cell precell(const double *q, const RpParams &, const double *auxv) {
+        Cell c;
+        for (int m = 0; m < NEQ; m++) c.q[m] = q[m];
+        c.rho = auxv[0];
+        c.un = fdiv_ieee(q[mu_of<IXY>()], c.rho);
+        c.sig = ps_sigma(q[0], auxv[1], auxv[2]);
+        c.c = dsqrt(fdiv_ieee(ps_sigmap(q[0], auxv[1], auxv[2]), c.rho));
+        c.z = c.c * c.rho;
+        return c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &, double (&s)[2]) {
+        s[0] = -L.c; s[1] = R.c;
+    }
+    template <int IXY>
+    __device__ static __forceinline__ void solve(const Cell &L, const Cell &R, const RpParams &,
+                                                 double (&wave)[2][NEQ], double (&s)[2], double (&amdq)[NEQ],
+                                                 double (&apdq)[NEQ]) {
+        constexpr int mu = mu_of<IXY>();
+        const double du = R.un - L.un;
+        const double dsig = R.sig - L.sig;
+        const double zs = L.z + R.z;
+        const double b1 = fdiv_ieee(-(R.z * du + dsig), zs);
+        const double b2 = fdiv_ieee(-(L.z * du - dsig), zs);
+        for (int m = 0; m < NEQ; m++) { wave[0][m] = 0.0; wave[1][m] = 0.0; }
+        wave[0][0] = b1; wave[0][mu] = b1 * L.z; s[0] = -L.c;
+        wave[1][0] = b2; wave[1][mu] = b2 * (-R.z); s[1] = R.c;
+        for (int m = 0; m < NEQ; m++) { amdq[m] = wave[0][m]; apdq[m] = wave[1][m]; }
+    }
+    // p-system only (NEQ == 3): auxb / auxa = (rho, K, flag, eps) of the rows below / above the cell asdq sits in
+    template <int IXY>
+    __device__ static __forceinline__ void transverse_vc(const Cell &, const double * /*auxo*/, const double *auxb,
+                                                         const double *auxa, const RpParams &,
+                                                         const double (&asdq)[NEQ], double (&bm)[NEQ], double (&bp)[NEQ]) {
+        constexpr int mu = mu_of<IXY>(), mv = NEQ == 3 ? 3 - mu : 0;
+        const double cm = dsqrt(fdiv_ieee(ps_sigmap(auxb[3], auxb[1], auxb[2]), auxb[0]));
+        const double cp = dsqrt(fdiv_ieee(ps_sigmap(auxa[3], auxa[1], auxa[2]), auxa[0]));
+        const double zm = cm * auxb[0], zp = cp * auxa[0];
+        const double b1 = fdiv_ieee(asdq[mv] + zp * asdq[0], zm + zp);
+        const double b3 = fdiv_ieee(zm * asdq[0] - asdq[mv], zm + zp);
+        for (int m = 0; m < NEQ; m++) { bm[m] = 0.0; bp[m] = 0.0; }
+        bm[0] = -cm * b1; bm[mv] = -cm * b1 * zm;
+        bp[0] = cp * b3;  bp[mv] = cp * b3 * (-zp);
+    }
+};
+using Elasticity1D = FwaveElastic<2>;
+using PSystem2D = FwaveElastic<3>;
+
 // ------------------------------------------------------------------------------------
 // Shallow water on the sphere (Calhoun, Helzel & LeVeque 2008), q = (h, hu, hv, hw) with Cartesian momentum;
 // third-party rpn2_shallow_sphere.f / rpt2_shallow_sphere.f (test/shallow_sphere/Makefile:7), restated; same

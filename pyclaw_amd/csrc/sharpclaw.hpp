@@ -5,6 +5,7 @@
 //   flux1                  src/fortran/2d/sharpclaw/flux1.f90:59-188   (char_decomp=0, no tfluct)
 //   weno5, PyWENO form     src/fortran/1d/sharpclaw/weno.f90:36-100    (lim_type=2)
 //   weno5, legacy form     src/fortran/1d/sharpclaw/reconstruct.f90:120-185 (lim_type=3)
+//   tvd2                   src/fortran/1d/sharpclaw/reconstruct.f90:568-625 (lim_type=1)
 //
 // Same mapping as the classic kernel (classic.hpp): one lane = one cell of a 64-cell strip, a
 // 64 x 16 tile staged through LDS, but a 3-cell halo (WENO5 needs q(i-2..i+2) and the update needs
@@ -108,6 +109,31 @@ __device__ __forceinline__ void weno5_legacy(double qm2, double qm1, double q0, 
     qr = weno5_legacy_edge(+1.0, dm1, d0, dp1, dp2, qm1, q0, qp1, qp2);
 }
 
+// reconstruct.f90:568-625 (tvd2) for one component of cell c: dqm = q(c) - q(c-1), dqp = q(c+1) - q(c);
+// meth = mthlim(m) -- indexed by COMPONENT in the reference.  (The Fortran reads an uninitialised dqm at the first
+// cell of each slice: ghost cell 0 only; see oracle/sharpclaw_oracle.c.  0/0 on constant data: v_max/min_f64 drop
+// the NaN like gfortran's MAX/MIN, ql = qr = q.)
+__device__ __forceinline__ void tvd2_cell(double qm1, double q0, double qp1, int meth, double &ql, double &qr) {
+    const double dqm = q0 - qm1, dqp = qp1 - q0;
+    const double r = fdiv_ieee(dqp, dqm);
+    double lim = 0.0;
+    switch (meth) {
+    case 1: lim = dmax(0.0, dmin(1.0, r)); break;
+    case 2: lim = dmax(dmax(0.0, dmin(1.0, 2.0 * r)), dmin(2.0, r)); break;
+    case 3: lim = fdiv_ieee(r + fabs(r), 1.0 + fabs(r)); break;
+    case 4: { const double c = (1.0 + r) / 2.0; lim = dmax(0.0, dmin(dmin(c, 2.0), 2.0 * r)); break; }
+    case 5: {
+        const double alpha = 1.0 / 3.0;
+        const double pp = fdiv_ieee(2.0 + r, 3.0);
+        const double amax = dmax(dmax(-alpha * r, 0.0), dmin(dmin(2.0 * r, pp), 2.0));
+        lim = dmax(0.0, dmin(pp, amax));
+        break;
+    }
+    }
+    qr = q0 + 0.5 * lim * dqm;
+    ql = q0 - 0.5 * lim * dqm;
+}
+
 // ---- the kernel ----------------------------------------------------------------------------------
 // x pass (IXY=1): dq(interior) = dq1d ; y pass (IXY=2): dq += dq1d   (flux2.f90:54-56,86-88)
 // y pass: rows of 16 doubles with the column XOR-swizzled by (al >> 1): a wavefront reading one column (lanes =
@@ -176,7 +202,8 @@ __global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, i
             const double qm2 = tile[stile_at<IXY>(m, lm2, ac)], qm1 = tile[stile_at<IXY>(m, lm1, ac)];
             const double q0 = tile[stile_at<IXY>(m, lane, ac)];
             const double qp1 = tile[stile_at<IXY>(m, lp1, ac)], qp2 = tile[stile_at<IXY>(m, lp2, ac)];
-            if (LIM == 2) weno5_pyweno(qm2, qm1, q0, qp1, qp2, ql[m], qr[m]);
+            if (LIM == 1) tvd2_cell(qm1, q0, qp1, a.mthlim[m < MAX_WAVES_K ? m : MAX_WAVES_K - 1], ql[m], qr[m]);
+            else if (LIM == 2) weno5_pyweno(qm2, qm1, q0, qp1, qp2, ql[m], qr[m]);
             else weno5_legacy(qm2, qm1, q0, qp1, qp2, ql[m], qr[m]);
         }
         double dtdx_c = a.dtd;

@@ -46,6 +46,10 @@ rp_advection_color_1d = RiemannSolver("advection_color_1d", 6, 1, 1, 1, [])     
 rp_burgers_1d = RiemannSolver("burgers_1d", 3, 1, 1, 1, [])
 rp_euler_1d = RiemannSolver("euler_1d", 4, 1, 3, 3, ["gamma", "gamma1"])            # rp1_euler_with_efix
 rp_shallow_1d = RiemannSolver("shallow_1d", 5, 1, 2, 2, ["g"])                       # rp1_shallow_roe_with_efix
+# f-wave solvers (solver.fwave = True, the reference's classic1fw / classic2fw): aux(1)=rho, aux(2)=K, aux(3)=1 for the
+# linear stress law, anything else for sigma = exp(K eps) - 1; the p-system's transverse solver reads aux(4) = eps
+rp_elasticity_fwave_1d = RiemannSolver("elasticity_fwave_1d", 7, 1, 2, 2, [])
+rp_psystem_fwave_2d = RiemannSolver("psystem_fwave_2d", 17, 2, 3, 2, [], True)
 rp_advection_2d = RiemannSolver("advection_2d", 12, 2, 1, 1, ["u", "v"], True)
 rp_shallow_2d = RiemannSolver("shallow_2d", 13, 2, 3, 3, ["g"], True)             # rpn2/rpt2_shallow_roe_with_efix
 rp_vc_acoustics_2d = RiemannSolver("vc_acoustics_2d", 14, 2, 3, 2, [], True)     # aux(1)=Z, aux(2)=c
@@ -60,7 +64,7 @@ rp_shallow_sphere_2d = RiemannSolver("shallow_sphere_2d", 16, 2, 4, 3, ["g"], Tr
 # rpn3_vc_acoustics.f; the transverse rpt3/rptt3 of the unsplit algorithm are not built: dim_split only)
 rp_vc_acoustics_3d = RiemannSolver("vc_acoustics_3d", 20, 3, 4, 2, [])
 
-_ALL = [rp_advection_1d, rp_acoustics_1d, rp_advection_color_1d, rp_burgers_1d, rp_euler_1d, rp_shallow_1d, rp_advection_2d, rp_shallow_2d, rp_vc_acoustics_2d, rp_vc_advection_2d, rp_acoustics_2d, rp_euler_5wave_2d, rp_shallow_sphere_2d, rp_vc_acoustics_3d]
+_ALL = [rp_elasticity_fwave_1d, rp_psystem_fwave_2d, rp_advection_1d, rp_acoustics_1d, rp_advection_color_1d, rp_burgers_1d, rp_euler_1d, rp_shallow_1d, rp_advection_2d, rp_shallow_2d, rp_vc_acoustics_2d, rp_vc_advection_2d, rp_acoustics_2d, rp_euler_5wave_2d, rp_shallow_sphere_2d, rp_vc_acoustics_3d]
 BY_NAME = dict((r.name, r) for r in _ALL)
 
 

@@ -203,8 +203,8 @@ class SharpClawSolver(Solver):
             raise Exception("Unrecognized value of solver.kernel_language.")
         if self.weno_order != 5:
             raise NotImplementedError("pyclaw_amd SharpClaw implements weno_order=5")
-        if self.lim_type not in (2, 3):
-            raise NotImplementedError("pyclaw_amd SharpClaw implements lim_type 2 (WENO5) and 3 (legacy WENO5)")
+        if self.lim_type not in (1, 2, 3):
+            raise NotImplementedError("pyclaw_amd SharpClaw implements lim_type 1 (tvd2), 2 (WENO5) and 3 (legacy WENO5)")
         if self.char_decomp != 0 or self.tfluct_solver:
             raise NotImplementedError("pyclaw_amd SharpClaw implements char_decomp=0, tfluct_solver=False")
         if self.time_integrator not in ('Euler', 'SSP33', 'SSP104'):
@@ -233,6 +233,8 @@ class SharpClawSolver(Solver):
         cfg.method[1] = 2
         cfg.method[5] = state.mcapa + 1
         cfg.method[6] = state.maux
+        for k, m in enumerate(self.mthlim[:_lib.MAX_WAVES]):      # clawparams.mthlim (sharpclaw.py:268): tvd2 reads it
+            cfg.mthlim[k] = int(m)
         cfg.fwave = int(bool(self.fwave))
         cfg.rp = rp.id
         for k, v in enumerate(params):

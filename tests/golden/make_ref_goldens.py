@@ -7,6 +7,7 @@ under /root/reference, oracle/Makefile) for the paths the reference ships no gol
   ref_step2ds_capa.npz     step2ds.f with a capacity function (mcapa = 2), ids = 1, 2
   ref_sharp_flux2.npz      SharpClaw flux2.f90, lim_type 2 (PyWENO weno5) and 3 (legacy weno5)
   ref_step2_unsplit_capa.npz  step2.f with a capacity function (mcapa = 2), method(3) = 0, 1, 2
+  ref_sharp_tvd2.npz       SharpClaw flux2.f90 with lim_type 1 (tvd2), mthlim 1..5
   ref_sphere_setup.npz     the shallow-sphere app's own setaux.f / qinit.f / src2.f / qcor.f (40 x 20 grid)
 
 Only inputs' SEEDS and the outputs are stored (inputs are regenerated from the seed by the tests).  Run in the
@@ -113,6 +114,16 @@ def main():
         out["dq_lim%d" % lim] = dq[:, mbc:-mbc, mbc:-mbc]
         out["cfl_lim%d" % lim] = cfl
     np.savez_compressed(os.path.join(HERE, "ref_sharp_flux2.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
+
+    # lim_type = 1: tvd2 (reconstruct.f90:568-625), every limiter id; a generic state (no constant patch, see
+    # oracle/sharpclaw_oracle.c).  The first interior row / column of the reference result depends on an
+    # uninitialised variable of the Fortran and is NOT compared by the tests.
+    out = {}
+    for lim in (1, 2, 3, 4, 5):
+        q0 = euler_state(50 + lim, shape)
+        dq, cfl = sref.sharp_flux2(O.RP_EULER5_2D, PAR, 1, 5, 0, mbc, mx, my, q0, None, dx, dy, dt, mthlim=[lim] * 5)
+        out["dq_mth%d" % lim] = dq[:, mbc:-mbc, mbc:-mbc]
+    np.savez_compressed(os.path.join(HERE, "ref_sharp_tvd2.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
     print("written:", [f for f in sorted(os.listdir(HERE)) if f.startswith("ref_")])
 
 

@@ -74,7 +74,41 @@ def test_oracle_step2_unsplit_capa(coracle, trans):
     assert np.array_equal(qn, z["q_trans%d" % trans]) and cfl == float(z["cfl_trans%d" % trans])
 
 
+@pytest.mark.parametrize("mth", [1, 2, 3, 4, 5])
+def test_oracle_sharp_tvd2(coracle, mth):
+    """lim_type = 1 (tvd2, reconstruct.f90:568-625).  Cells of the first interior row / column are left out: there the
+    Fortran reads an uninitialised variable (oracle/sharpclaw_oracle.c: tvd2)."""
+    z = load("ref_sharp_tvd2.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 3)
+    q0 = G.euler_state(50 + mth, shape)
+    coracle.set_sharp_mthlim([mth] * 5)
+    dq, _ = coracle.sharp_flux2(O.RP_EULER5_2D, G.PAR, 1, 5, 0, 3, mx, my, q0, None, dx, dy, dt)
+    assert np.array_equal(dq[:, 4:-3, 4:-3], z["dq_mth%d" % mth][:, 1:, 1:])
+
+
 # ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("mth", [1, 2, 3, 4, 5])
+def test_hip_sharp_tvd2(coracle, mth):
+    from pyclaw_amd import _lib as L
+    z = load("ref_sharp_tvd2.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 3)
+    q0 = G.euler_state(50 + mth, shape)
+    dq = np.zeros_like(q0)
+    cfl = C.c_double()
+    mthlim = np.array([mth] * 5, dtype=np.int32)
+    L.check(L.lib().pcl_sharp_module_mthlim(L.i(mthlim), 5))
+    try:
+        L.check(L.lib().pcl_sharp_flux2(O.RP_EULER5_2D, L.d(np.array(G.PAR + [0.0] * 6)), 1, 5, 5, 0, 0, 3, mx, my,
+                                        L.d(q0), L.d(dq), None, dx, dy, dt, C.cast(C.byref(cfl), L.dp)))
+    finally:
+        L.check(L.lib().pcl_sharp_module_mthlim(L.i(np.ones(5, dtype=np.int32)), 5))
+    assert np.array_equal(dq[:, 4:-3, 4:-3], z["dq_mth%d" % mth][:, 1:, 1:])     # the reference's own Fortran
+    coracle.set_sharp_mthlim([mth] * 5)
+    ref, cfl_ref = coracle.sharp_flux2(O.RP_EULER5_2D, G.PAR, 1, 5, 0, 3, mx, my, q0, None, dx, dy, dt)
+    assert np.array_equal(dq[:, 3:-3, 3:-3], ref[:, 3:-3, 3:-3]) and cfl.value == cfl_ref   # every cell vs the oracle
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("trans", [0, 1, 2])
 def test_hip_step2_unsplit_capa(trans):
