@@ -124,6 +124,9 @@ int pcl_version(void);
 int pcl_device_count(void);                     /* never initialises a context          */
 
 /* ---- layer 1: f2py-shaped stateless calls on host arrays ---------------------------- */
+/* Stateless for the caller like the f2py modules; internally the device buffers of the last call are kept and reused
+ * while the array shapes stay the same.  pcl_layer1_release() frees them (optional: also done at unload). */
+void pcl_layer1_release(void);
 /* classic1.step1(mbc,mx,q,aux,dx,dt,method,mthlim) -> (q,cfl)   step1.f:4-5, clawpack.py:323.
  * q(meqn,1-mbc:mx+mbc) is updated in place for cells 1..mx (the two ghost cells the
  * Fortran also touches are left unchanged: no caller reads them, clawpack.py:406). */
@@ -158,6 +161,14 @@ int pcl_step2(int rp, const double *rp_params, int fwave, int meqn, int mwaves, 
 int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx, int my,
                 int mz, const double *qold, double *qnew, const double *aux, double dx, double dy, double dz,
                 double dt, const int *method, const int *mthlim, double *cfl, int idir);
+
+/* classic3.step3(maxm,mbc,mx,my,mz,qold,qnew,aux,dx,dy,dz,dt,method,mthlim,aux1,aux2,aux3,work) -> (qnew,cfl)
+ * src/fortran/3d/classic/step3.f:2-6, clawpack.py:690-696: the UNSPLIT 3-D step with the transverse solves rpt3 / rptt3
+ * (flux3.f:260-593); method[2] = order_trans = 0, 10, 11, 20, 21 or 22.  Interior cells of qnew are updated, ghost
+ * cells returned unchanged. */
+int pcl_step3(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx, int my, int mz,
+              const double *qold, double *qnew, const double *aux, double dx, double dy, double dz, double dt,
+              const int *method, const int *mthlim, double *cfl);
 
 /* sharpclaw1.flux1(q,aux,dt,t,ixy,mx,mbc,maxnx) -> (dq,cfl)   1d/sharpclaw/flux1.f90, sharpclaw.py:385
  * sharpclaw2.flux2(q,aux,dt,t,mbc,maxm,mx,my)   -> (dq,cfl)   2d/sharpclaw/flux2.f90:2, sharpclaw.py:558

@@ -162,8 +162,11 @@ def step_hyperbolic(p, backend):
         qnew = p.qbc
         qold = qnew.copy("F")
         dx, dy, dz = p.d
-        if not p.dim_split:
-            raise NotImplementedError("unsplit 3-D (step3) is not restated")
+        if not p.dim_split:                                 # clawpack.py:690-696: classic3.step3
+            _, cfl = backend.step3(p.rp, maxm, mbc, mx, my, mz, qold, qnew, p.auxbc, dx, dy, dz, p.dt, p.method, p.mthlim)
+            p.cfl = cfl
+            p.q = p.qbc[inner]
+            return
         cfl = 0.0
         for idir, qo in ((1, qold), (2, qnew), (3, qnew)):
             _, c1 = backend.step3ds(p.rp, maxm, mbc, mx, my, mz, qo, qnew, p.auxbc, dx, dy, dz, p.dt,

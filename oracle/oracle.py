@@ -72,6 +72,8 @@ class COracle:
         L.orc_step2.argtypes = L.orc_step2ds.argtypes[:-1]
         L.orc_step3ds.restype = C.c_int
         L.orc_step3ds.argtypes = [C.c_int] * 9 + [_dp, _dp, _dp] + [C.c_double] * 4 + [_ip, _ip, _dp, C.c_int]
+        L.orc_step3.restype = C.c_int
+        L.orc_step3.argtypes = L.orc_step3ds.argtypes[:-1]
         L.orc_step1.restype = C.c_int
         L.orc_step1.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
                                 C.c_double, C.c_double, _ip, _ip, _dp]
@@ -142,6 +144,21 @@ class COracle:
                                   dx, dy, dz, dt, _i(method), _i(mthlim), C.byref(cfl), idir)
         if rc:
             raise RuntimeError("oracle step3ds: rc=%d (unknown Riemann solver / unsplit 3-D not restated)" % rc)
+        return qnew, cfl.value
+
+    def step3(self, rp, maxm, mbc, mx, my, mz, qold, qnew, aux, dx, dy, dz, dt, method, mthlim):
+        """classic3.step3(...) -> (qnew, cfl) (clawpack.py:690-696): the unsplit 3-D algorithm (step3.f + flux3.f)"""
+        meqn = qnew.shape[0]
+        method = np.ascontiguousarray(method, dtype=np.int32)
+        mthlim = np.ascontiguousarray(mthlim, dtype=np.int32)
+        maux = int(method[6])
+        auxp = _d(aux) if (aux is not None and maux > 0) else _d(np.zeros(1))
+        cfl = C.c_double(0.0)
+        assert qnew.flags.f_contiguous and qold.flags.f_contiguous
+        rc = self.lib.orc_step3(rp, maxm, meqn, len(mthlim), maux, mbc, mx, my, mz, _d(qold), _d(qnew), auxp,
+                                dx, dy, dz, dt, _i(method), _i(mthlim), C.byref(cfl))
+        if rc:
+            raise RuntimeError("oracle step3: rc=%d" % rc)
         return qnew, cfl.value
 
     def step2(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim,

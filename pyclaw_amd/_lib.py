@@ -48,6 +48,7 @@ PROTOTYPES = {
     "pcl_last_error": (C.c_char_p, []),
     "pcl_version": (C.c_int, []),
     "pcl_device_count": (C.c_int, []),
+    "pcl_layer1_release": (None, []),
     "pcl_step1": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp,
                             C.c_double, C.c_double, ip, ip, dp]),
     "pcl_step1fw": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp,
@@ -58,6 +59,7 @@ PROTOTYPES = {
     "pcl_step2": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_double, ip, ip, dp]),
     "pcl_step3ds": (C.c_int, [C.c_int, dp] + [C.c_int] * 7 + [dp, dp, dp] + [C.c_double] * 4 + [ip, ip, dp, C.c_int]),
+    "pcl_step3": (C.c_int, [C.c_int, dp] + [C.c_int] * 7 + [dp, dp, dp] + [C.c_double] * 4 + [ip, ip, dp]),
     "pcl_sharp_module_mthlim": (C.c_int, [ip, C.c_int]),
     "pcl_sharp_flux1": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   dp, dp, dp, C.c_double, C.c_double, dp]),

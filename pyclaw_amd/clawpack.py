@@ -264,8 +264,8 @@ class ClawSolver2D(ClawSolver):
 
 
 class ClawSolver3D(ClawSolver):
-    r"""3D classic solver (clawpack.py:563-702).  ``dim_split=True`` (Godunov splitting, ``step3ds``) runs on
-    the device; the unsplit algorithm with ``rpt3``/``rptt3`` transverse solves is not built yet."""
+    r"""3D classic solver (clawpack.py:563-702): ``dim_split=True`` (Godunov splitting, ``step3ds``) or the unsplit
+    algorithm with the ``rpt3``/``rptt3`` transverse solves (``step3``; ``order_trans`` 0, 10, 11, 20, 21, 22)."""
 
     no_trans = 0
     trans_inc = 11
@@ -278,7 +278,4 @@ class ClawSolver3D(ClawSolver):
         super(ClawSolver3D, self).__init__(data)
 
     def setup(self, solution):
-        if not self.dim_split:
-            raise NotImplementedError("pyclaw_amd ClawSolver3D implements dim_split=True (step3ds); "
-                                      "the unsplit step3 with rpt3/rptt3 is not built")
         super(ClawSolver3D, self).setup(solution)

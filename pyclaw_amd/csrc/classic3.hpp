@@ -1,0 +1,350 @@
+// classic3.hpp -- the UNSPLIT 3-D classic algorithm (step3.f + the transverse part of flux3.f) as gfx950 kernels.
+//
+// Reference path restated (operation order preserved; oracle: oracle/classic_oracle.c flux3_full / orc_step3):
+//   flux3.f:168-258   normal solve, Godunov increment, CFL, limiter, cqxx / fadd        (as the dim-split sweep)
+//   flux3.f:260-593   rpt3 x4 (+4 for the correction waves), rptt3 x8, gadd / hadd accumulation
+//   step3.f:114-592   x, y, z sweeps over slices 0..m+1; every slice updates the 3 x 3 cells around it
+//
+// Two kernels per direction.  slices3_kernel: one lane = one cell of a 64-cell strip (like sweep3_kernel); it leaves
+// the slice's pieces for each cell -- qadd, fadd(i+1)-fadd(i), gadd(2,-1:1), hadd(2,-1:1): 14 values per component --
+// in scratch planes.  combine3_kernel: every interior cell gathers the nine slices around it IN THE ORDER the
+// Fortran's loop nest visits them (x and z sweeps: z-like index outer, y-like inner; y sweep: y-like outer) and
+// applies their updates with the reference's association.  All three directions read the same qold, and the
+// x, y, z contributions are added in that order, exactly like step3.f.  (Throughput was not the aim of this first
+// device version: 14 scratch values per component and direction move ~20x the algorithmic bytes.)
+//
+// Direction roles (step3.f:176,303,470): sweep DIR, y-like = DIR+1, z-like = DIR+2 (cyclic).  aux block of a cell:
+// blk[oe+1][of+1][k] = aux component k of the neighbour at y-like offset oe, z-like offset of.
+#pragma once
+#include "classic.hpp"
+
+namespace pcl {
+namespace PCL_NS {
+
+struct Slices3Args {
+    double *scr[14];     // [0] qadd, [1] fadd(i+1)-fadd(i), [2+3*(side-1)+(slice+1)] gadd, [8+...] hadd; MEQN planes each
+    long s_e, s_f;       // strides (doubles) of the y-like and z-like directions
+    int n_e, n_f;        // extents with ghost cells
+    int lo_e, hi_e, lo_f, hi_f;   // swept slices: 0..m+1 in both transverse directions (ghost-offset indices)
+    int m3, m4;          // method(3) = 10*m3 + m4
+    double dty, dtz;     // dt / d(y-like), dt / d(z-like)
+};
+
+template <class RP, int DIR>
+__device__ __forceinline__ void load_blk(const SweepArgs &a, const Slices3Args &t, long g, int ce, int cf,
+                                         double (&blk)[3][3][RP::NAUX]) {
+#pragma unroll
+    for (int oe = -1; oe <= 1; oe++)
+#pragma unroll
+        for (int of = -1; of <= 1; of++) {
+            // clamp: the outermost slices' far neighbours do not exist; their results are never used (step3.f sweeps
+            // 0..m+1 with mbc = 2, so every USED block lies inside the array)
+            const int de = (ce + oe < 0) ? 0 : (ce + oe >= t.n_e ? 0 : oe);
+            const int df = (cf + of < 0) ? 0 : (cf + of >= t.n_f ? 0 : of);
+#pragma unroll
+            for (int k = 0; k < RP::NAUX; k++)
+                blk[oe + 1][of + 1][k] = a.aux[aux_idx<RP, DIR>(k) * a.plane + g + de * t.s_e + df * t.s_f];
+        }
+}
+
+template <class RP, int DIR>
+__global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t, int ntiles_al) {
+    constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES, NAUX = RP::NAUX;
+    using Cell = typename RP::Cell;
+    // grid: x = strips along the sweep, y = y-like index, z = z-like index; 4 wavefronts = 4 consecutive y-like rows
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const int ta = blockIdx.x % ntiles_al;
+    const int ce = (blockIdx.x / ntiles_al) * 4 + wv + t.lo_e;
+    const int cf = blockIdx.y + t.lo_f;
+    if (ce > t.hi_e) return;                                   // wave-uniform
+    const int a0 = a.mbc - HALO + ta * STRIP;
+    const int ca = a0 + lane;
+    const int cc = ca < a.n_al ? ca : a.n_al - 1;
+    const long g = (long)cc * a.s_al + (long)ce * t.s_e + (long)cf * t.s_f;
+    const long gl = (long)(cc > 0 ? cc - 1 : 0) * a.s_al + (long)ce * t.s_e + (long)cf * t.s_f;
+    double q[MEQN], auxv[NAUX];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + g];
+#pragma unroll
+    for (int k = 0; k < NAUX; k++) auxv[k] = a.aux[aux_idx<RP, DIR>(k) * a.plane + g];
+    double blkR[3][3][NAUX], blkL[3][3][NAUX];
+    load_blk<RP, DIR>(a, t, g, ce, cf, blkR);     // cell l: A^+ dq of interface l sits here
+    load_blk<RP, DIR>(a, t, gl, ce, cf, blkL);    // cell l-1: A^- dq
+
+    const double d = a.dtd;
+    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
+    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.m_al) && lane >= HALO && lane < WAVE - HALO;
+    double cflmax = 0.0;
+
+    const Cell cR = RP::template precell<DIR>(q, a.par, auxv);
+    const Cell cL = struct_from_left(cR);
+    double wave[MWAVES][MEQN], s[MWAVES], amdq[MEQN], apdq[MEQN];
+    RP::template solve<DIR>(cL, cR, a.par, wave, s, amdq, apdq);
+    cfl_accumulate<false, MWAVES>(s, d, d, cfl_ok, cflmax);
+
+    double cq[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) cq[m] = 0.0;
+    if (a.order != 1) {
+        // limiter.f:33-57 (same code as lane_core, without its wave-uniform skips)
+#pragma unroll
+        for (int mw = 0; mw < MWAVES; mw++) {
+            const int lim = a.mthlim[mw];
+            if (lim == 0) continue;
+            double wn = 0.0, dl = 0.0;
+            bool first = true;
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                if (!RP::template nz<DIR>(mw, m)) continue;
+                const double w = wave[mw][m], wl = from_left(w);
+                wn = first ? w * w : wn + w * w;
+                dl = first ? wl * w : dl + wl * w;
+                first = false;
+            }
+            const double dr = from_right(dl);
+            if (wn != 0.0) {
+                const double phi = philim(wn, s[mw] > 0.0 ? dl : dr, lim);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++)
+                    if (RP::template nz<DIR>(mw, m)) wave[mw][m] = phi * wave[mw][m];
+            }
+        }
+        const double dtdxave = 0.5 * (d + d);
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {       // flux3.f:244-247
+            double c = 0.0;
+            bool first = true;
+#pragma unroll
+            for (int mw = 0; mw < MWAVES; mw++)
+                if (RP::template nz<DIR>(mw, m)) {
+                    const double sa = fabs(s[mw]);
+                    const double term = 0.5 * sa * (1.0 - sa * dtdxave) * wave[mw][m];
+                    c = first ? term : c + term;
+                    first = false;
+                }
+            cq[m] = c;
+        }
+    }
+    double qadd[MEQN], df[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) {
+        const double amdq_r = from_right(amdq[m]), fadd_r = from_right(cq[m]);
+        qadd[m] = -(d * apdq[m]) - d * amdq_r;
+        df[m] = fadd_r - cq[m];
+    }
+
+    double gadd[2][3][MEQN], hadd[2][3][MEQN];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) { gadd[k][j][m] = 0.0; hadd[k][j][m] = 0.0; }
+
+    if (t.m3 > 0) {
+        // ---- transverse splits of the fluctuations (flux3.f:269-291) and of the correction waves (:299-321)
+        double bmamdq[MEQN], bpamdq[MEQN], bmapdq[MEQN], bpapdq[MEQN];
+        double cmamdq[MEQN], cpamdq[MEQN], cmapdq[MEQN], cpapdq[MEQN];
+        RP::template transverse3<DIR>(2, blkL, amdq, bmamdq, bpamdq);
+        RP::template transverse3<DIR>(2, blkR, apdq, bmapdq, bpapdq);
+        RP::template transverse3<DIR>(3, blkL, amdq, cmamdq, cpamdq);
+        RP::template transverse3<DIR>(3, blkR, apdq, cmapdq, cpapdq);
+        double bmcqxxm[MEQN], bpcqxxm[MEQN], bmcqxxp[MEQN], bpcqxxp[MEQN];
+        double cmcqxxm[MEQN], cpcqxxm[MEQN], cmcqxxp[MEQN], cpcqxxp[MEQN];
+#pragma unroll
+        for (int m = 0; m < MEQN; m++)
+            bmcqxxm[m] = bpcqxxm[m] = bmcqxxp[m] = bpcqxxp[m] = cmcqxxm[m] = cpcqxxm[m] = cmcqxxp[m] = cpcqxxp[m] = 0.0;
+        if (t.m3 == 2) {
+            RP::template transverse3<DIR>(2, blkL, cq, bmcqxxm, bpcqxxm);
+            RP::template transverse3<DIR>(2, blkR, cq, bmcqxxp, bpcqxxp);
+            RP::template transverse3<DIR>(3, blkL, cq, cmcqxxm, cpcqxxm);
+            RP::template transverse3<DIR>(3, blkR, cq, cmcqxxp, cpcqxxp);
+        }
+        const double k6z = (1.0 / 6.0) * d * t.dtz, k6y = (1.0 / 6.0) * d * t.dty;
+        double bmcpapdq[MEQN], bpcpapdq[MEQN], bmcpamdq[MEQN], bpcpamdq[MEQN];
+        double bmcmapdq[MEQN], bpcmapdq[MEQN], bmcmamdq[MEQN], bpcmamdq[MEQN];
+#pragma unroll
+        for (int m = 0; m < MEQN; m++)
+            bmcpapdq[m] = bpcpapdq[m] = bmcpamdq[m] = bpcpamdq[m] = bmcmapdq[m] = bpcmapdq[m] = bmcmamdq[m] = bpcmamdq[m] = 0.0;
+
+        // ---- G fluxes (y-like), flux3.f:347-452
+        if (t.m4 > 0) {
+            double cpapdq2[MEQN], cpamdq2[MEQN], cmapdq2[MEQN], cmamdq2[MEQN];
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                if (t.m4 == 2) {
+                    cpapdq2[m] = cpapdq[m] - 3.0 * cpcqxxp[m];
+                    cpamdq2[m] = cpamdq[m] + 3.0 * cpcqxxm[m];
+                    cmapdq2[m] = cmapdq[m] - 3.0 * cmcqxxp[m];
+                    cmamdq2[m] = cmamdq[m] + 3.0 * cmcqxxm[m];
+                } else {
+                    cpapdq2[m] = cpapdq[m]; cpamdq2[m] = cpamdq[m]; cmapdq2[m] = cmapdq[m]; cmamdq2[m] = cmamdq[m];
+                }
+            }
+            RP::template transverse3t<DIR>(2, 2, blkR, cpapdq2, bmcpapdq, bpcpapdq);
+            RP::template transverse3t<DIR>(2, 2, blkL, cpamdq2, bmcpamdq, bpcpamdq);
+            RP::template transverse3t<DIR>(2, 1, blkR, cmapdq2, bmcmapdq, bpcmapdq);
+            RP::template transverse3t<DIR>(2, 1, blkL, cmamdq2, bmcmamdq, bpcmamdq);
+        }
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {
+            // the A^- parts of interface l+1 belong to this cell: they arrive from the right-hand lane
+            const double r_bmamdq = from_right(bmamdq[m]), r_bpamdq = from_right(bpamdq[m]);
+            const double r_bmcpamdq = from_right(bmcpamdq[m]), r_bpcpamdq = from_right(bpcpamdq[m]);
+            const double r_bmcmamdq = from_right(bmcmamdq[m]), r_bpcmamdq = from_right(bpcmamdq[m]);
+            const double r_bmcqxxm = from_right(bmcqxxm[m]), r_bpcqxxm = from_right(bpcqxxm[m]);
+            double g10 = 0.0, g20 = 0.0, g21 = 0.0, g11 = 0.0, g2m = 0.0, g1m = 0.0;
+            // iteration i = l of flux3.f's loop 180 (index i)
+            g10 = g10 - 0.5 * d * bmapdq[m];
+            g20 = g20 - 0.5 * d * bpapdq[m];
+            if (t.m4 > 0) {
+                g20 = g20 + k6z * (bpcpapdq[m] - bpcmapdq[m]);
+                g10 = g10 + k6z * (bmcpapdq[m] - bmcmapdq[m]);
+                g21 = g21 - k6z * bpcpapdq[m];
+                g11 = g11 - k6z * bmcpapdq[m];
+                g2m = g2m + k6z * bpcmapdq[m];
+                g1m = g1m + k6z * bmcmapdq[m];
+            }
+            if (t.m3 >= 2) {
+                g20 = g20 + d * bpcqxxp[m];
+                g10 = g10 + d * bmcqxxp[m];
+            }
+            // iteration i = l+1 (index i-1)
+            g10 = g10 - 0.5 * d * r_bmamdq;
+            g20 = g20 - 0.5 * d * r_bpamdq;
+            if (t.m4 > 0) {
+                g20 = g20 + k6z * (r_bpcpamdq - r_bpcmamdq);
+                g10 = g10 + k6z * (r_bmcpamdq - r_bmcmamdq);
+                g21 = g21 - k6z * r_bpcpamdq;
+                g11 = g11 - k6z * r_bmcpamdq;
+                g2m = g2m + k6z * r_bpcmamdq;
+                g1m = g1m + k6z * r_bmcmamdq;
+            }
+            if (t.m3 >= 2) {
+                g20 = g20 - d * r_bpcqxxm;
+                g10 = g10 - d * r_bmcqxxm;
+            }
+            gadd[0][1][m] = g10; gadd[1][1][m] = g20; gadd[1][2][m] = g21; gadd[0][2][m] = g11;
+            gadd[1][0][m] = g2m; gadd[0][0][m] = g1m;
+        }
+        // ---- H fluxes (z-like), flux3.f:462-590
+        if (t.m4 == 2) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                bpapdq[m] = bpapdq[m] - 3.0 * bpcqxxp[m];
+                bpamdq[m] = bpamdq[m] + 3.0 * bpcqxxm[m];
+                bmapdq[m] = bmapdq[m] - 3.0 * bmcqxxp[m];
+                bmamdq[m] = bmamdq[m] + 3.0 * bmcqxxm[m];
+            }
+        }
+        if (t.m4 > 0) {
+            RP::template transverse3t<DIR>(3, 2, blkR, bpapdq, bmcpapdq, bpcpapdq);
+            RP::template transverse3t<DIR>(3, 2, blkL, bpamdq, bmcpamdq, bpcpamdq);
+            RP::template transverse3t<DIR>(3, 1, blkR, bmapdq, bmcmapdq, bpcmapdq);
+            RP::template transverse3t<DIR>(3, 1, blkL, bmamdq, bmcmamdq, bpcmamdq);
+        }
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {
+            const double r_cmamdq = from_right(cmamdq[m]), r_cpamdq = from_right(cpamdq[m]);
+            const double r_bmcpamdq = from_right(bmcpamdq[m]), r_bpcpamdq = from_right(bpcpamdq[m]);
+            const double r_bmcmamdq = from_right(bmcmamdq[m]), r_bpcmamdq = from_right(bpcmamdq[m]);
+            const double r_cmcqxxm = from_right(cmcqxxm[m]), r_cpcqxxm = from_right(cpcqxxm[m]);
+            double h10 = 0.0, h20 = 0.0, h21 = 0.0, h11 = 0.0, h2m = 0.0, h1m = 0.0;
+            h10 = h10 - 0.5 * d * cmapdq[m];
+            h20 = h20 - 0.5 * d * cpapdq[m];
+            if (t.m4 > 0) {
+                h20 = h20 + k6y * (bpcpapdq[m] - bpcmapdq[m]);
+                h10 = h10 + k6y * (bmcpapdq[m] - bmcmapdq[m]);
+                h21 = h21 - k6y * bpcpapdq[m];
+                h11 = h11 - k6y * bmcpapdq[m];
+                h2m = h2m + k6y * bpcmapdq[m];
+                h1m = h1m + k6y * bmcmapdq[m];
+            }
+            if (t.m3 >= 2) {
+                h20 = h20 + d * cpcqxxp[m];
+                h10 = h10 + d * cmcqxxp[m];
+            }
+            h10 = h10 - 0.5 * d * r_cmamdq;
+            h20 = h20 - 0.5 * d * r_cpamdq;
+            if (t.m4 > 0) {
+                h20 = h20 + k6y * (r_bpcpamdq - r_bpcmamdq);
+                h10 = h10 + k6y * (r_bmcpamdq - r_bmcmamdq);
+                h21 = h21 - k6y * r_bpcpamdq;
+                h11 = h11 - k6y * r_bmcpamdq;
+                h2m = h2m + k6y * r_bpcmamdq;
+                h1m = h1m + k6y * r_bmcmamdq;
+            }
+            if (t.m3 >= 2) {
+                h20 = h20 - d * r_cpcqxxm;
+                h10 = h10 - d * r_cmcqxxm;
+            }
+            hadd[0][1][m] = h10; hadd[1][1][m] = h20; hadd[1][2][m] = h21; hadd[0][2][m] = h11;
+            hadd[1][0][m] = h2m; hadd[0][0][m] = h1m;
+        }
+    }
+    if (owned) {
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {
+            const long at = m * a.plane + g;
+            t.scr[0][at] = qadd[m];
+            t.scr[1][at] = df[m];
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    t.scr[2 + 3 * k + j][at] = gadd[k][j][m];
+                    t.scr[8 + 3 * k + j][at] = hadd[k][j][m];
+                }
+        }
+    }
+    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
+}
+
+// One thread per cell: qacc(T) += the nine slices of direction DIR around T, in the loop order of step3.f
+struct Combine3Args {
+    const double *scr[14];
+    const double *qsrc;   // qold for the x direction (qacc starts as a copy), qacc itself afterwards
+    double *qacc;
+    long plane, s_al, s_e, s_f;
+    int n_al, n_e, n_f, mbc, m_al, m_e, m_f, meqn;
+    double dtd, dty, dtz;
+    int e_outer;          // 1: the Fortran's outer loop runs over the y-like index (y sweep), 0: over the z-like one
+    int first;            // 1: x direction (start from qsrc and write every cell, ghost cells copied through)
+};
+__global__ __launch_bounds__(256) void combine3_kernel(Combine3Args c) {
+    const int ia = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ie = blockIdx.y, jf = blockIdx.z;
+    if (ia >= c.n_al) return;
+    const long g = (long)ia * c.s_al + (long)ie * c.s_e + (long)jf * c.s_f;
+    const bool interior = ia >= c.mbc && ia < c.mbc + c.m_al && ie >= c.mbc && ie < c.mbc + c.m_e && jf >= c.mbc &&
+                          jf < c.mbc + c.m_f;
+    for (int m = 0; m < c.meqn; m++) {
+        const long at = m * c.plane + g;
+        double q = c.first ? c.qsrc[at] : c.qacc[at];
+        if (interior) {
+            for (int o = 1; o >= -1; o--)
+                for (int in = 1; in >= -1; in--) {
+                    const int oe = c.e_outer ? o : in, of = c.e_outer ? in : o;
+                    const long S = at - oe * c.s_e - of * c.s_f;      // the slice that adds to (oe, of) from itself
+#define G_(k, j) c.scr[2 + 3 * ((k)-1) + ((j) + 1)][S]
+#define H_(k, j) c.scr[8 + 3 * ((k)-1) + ((j) + 1)][S]
+                    if (oe == 0 && of == 0)
+                        q = q + c.scr[0][S] - c.dtd * c.scr[1][S] - c.dty * (G_(2, 0) - G_(1, 0)) - c.dtz * (H_(2, 0) - H_(1, 0));
+                    else if (oe == -1 && of == 0) q = q - c.dty * G_(1, 0) - c.dtz * (H_(2, -1) - H_(1, -1));
+                    else if (oe == -1 && of == -1) q = q - c.dty * G_(1, -1) - c.dtz * H_(1, -1);
+                    else if (oe == 0 && of == -1) q = q - c.dty * (G_(2, -1) - G_(1, -1)) - c.dtz * H_(1, 0);
+                    else if (oe == 1 && of == -1) q = q + c.dty * G_(2, -1) - c.dtz * H_(1, 1);
+                    else if (oe == 1 && of == 0) q = q + c.dty * G_(2, 0) - c.dtz * (H_(2, 1) - H_(1, 1));
+                    else if (oe == 1 && of == 1) q = q + c.dty * G_(2, 1) + c.dtz * H_(2, 1);
+                    else if (oe == 0 && of == 1) q = q - c.dty * (G_(2, 1) - G_(1, 1)) + c.dtz * H_(2, 0);
+                    else q = q - c.dty * G_(1, 1) + c.dtz * H_(2, -1);
+#undef G_
+#undef H_
+                }
+        }
+        if (interior || c.first) c.qacc[at] = q;
+    }
+}
+
+}  // namespace PCL_NS
+}  // namespace pcl

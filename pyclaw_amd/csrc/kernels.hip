@@ -12,6 +12,7 @@
 #include "../../include/pyclaw_amd.h"
 #include "classic.hpp"
 #include "sharpclaw.hpp"
+#include "classic3.hpp"
 
 namespace pcl {
 namespace PCL_NS {
@@ -112,6 +113,43 @@ int launch_sweep3(const SweepLaunch &l, std::string &err) {
     else hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 3>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep3 launch", e);
+}
+
+// unsplit 3-D step, one direction: slices3_kernel into the scratch planes, then combine3_kernel (classic3.hpp)
+namespace {
+template <class RP, int DIR> int launch_unsplit3_t(const Unsplit3Launch &l, std::string &err) {
+    const SweepArgs &a = l.a;
+    Slices3Args t;
+    for (int k = 0; k < 14; k++) t.scr[k] = l.scr[k];
+    t.s_e = l.s_e; t.s_f = l.s_f; t.n_e = l.n_e; t.n_f = l.n_f;
+    t.lo_e = a.mbc - 1; t.hi_e = a.mbc + l.m_e; t.lo_f = a.mbc - 1; t.hi_f = a.mbc + l.m_f;
+    t.m3 = l.m3; t.m4 = l.m4; t.dty = l.dty; t.dtz = l.dtz;
+    const int ntiles_al = (a.m_al + STRIP - 1) / STRIP;
+    const int rows = l.m_e + 2, rowtiles = (rows + 3) / 4;
+    hipLaunchKernelGGL((slices3_kernel<RP, DIR>), dim3((unsigned)ntiles_al * rowtiles, (unsigned)(l.m_f + 2)), dim3(256), 0,
+                       l.stream, a, t, ntiles_al);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, "slices3 launch", e);
+    Combine3Args c;
+    for (int k = 0; k < 14; k++) c.scr[k] = l.scr[k];
+    c.qsrc = a.qin; c.qacc = l.qacc; c.plane = a.plane; c.s_al = a.s_al; c.s_e = l.s_e; c.s_f = l.s_f;
+    c.n_al = a.n_al; c.n_e = l.n_e; c.n_f = l.n_f; c.mbc = a.mbc; c.m_al = a.m_al; c.m_e = l.m_e; c.m_f = l.m_f;
+    c.meqn = RP::MEQN; c.dtd = a.dtd; c.dty = l.dty; c.dtz = l.dtz;
+    c.e_outer = DIR == 2 ? 1 : 0;       // step3.f: y sweeps loop k (their y-like index) outside, x and z sweeps inside
+    c.first = DIR == 1 ? 1 : 0;
+    hipLaunchKernelGGL(combine3_kernel, dim3((unsigned)((a.n_al + 255) / 256), (unsigned)l.n_e, (unsigned)l.n_f), dim3(256), 0,
+                       l.stream, c);
+    e = hipGetLastError();
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "combine3 launch", e);
+}
+}  // namespace
+
+int launch_unsplit3(const Unsplit3Launch &l, std::string &err) {
+    if (l.rp != PCL_RP_VC_ACOUSTICS_3D) { err = "Riemann solver id is not a 3-D solver with transverse solvers"; return PCL_EINVAL; }
+    if (l.a.mcapa > 0) { err = "3-D: capacity function not implemented"; return PCL_EINVAL; }
+    if (l.dir == 1) return launch_unsplit3_t<VcAcoustics3D, 1>(l, err);
+    if (l.dir == 2) return launch_unsplit3_t<VcAcoustics3D, 2>(l, err);
+    return launch_unsplit3_t<VcAcoustics3D, 3>(l, err);
 }
 
 #if !PCL_FAST

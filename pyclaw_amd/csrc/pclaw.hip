@@ -43,6 +43,8 @@ struct pcl_solver {
     double *aux = nullptr;
     double *sreg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // SharpClaw registers (0 aliases q)
     int sel = 0;          // register the put/get/bc/strip/halo calls act on
+    double *scr3[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, nullptr};   // unsplit 3-D slice pieces
     double *scr[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // unsplit slice pieces ([9], [10]: qcor of the x / y slices)
     double *stage = nullptr;  // AoS staging for host transfers (qbc-sized)
     size_t stage_bytes = 0;
@@ -380,6 +382,48 @@ int do_sweep3(pcl_solver *s, const double *qin, double *qout, int dir, double dt
     return rc;
 }
 
+// unsplit 3-D step (step3.f): for x, y, z in turn, every slice's pieces into scratch planes and the ordered combine into
+// t1 (kernels in classic3.hpp).  All three directions read the same qold = q.
+int do_unsplit3(pcl_solver *s, double dt) {
+    const int m3 = s->cfg.method[2] / 10, m4 = s->cfg.method[2] - 10 * m3;
+    if (m3 < 0 || m3 > 2 || m4 < 0 || m4 > 2 || (m4 > 0 && m3 == 0))
+        return fail(PCL_EINVAL, "3-D order_trans must be 0, 10, 11, 20, 21 or 22 (flux3.f:46-73)");
+    const size_t qbytes = ((size_t)s->total + 16) * sizeof(double);
+    for (int k = 0; k < 14; k++) {
+        if (s->scr3[k]) continue;
+        double *raw = nullptr;
+        HIP_TRY(hipMalloc((void **)&raw, qbytes));
+        HIP_TRY(hipMemsetAsync(raw, 0, qbytes, s->stream));
+        s->scr3[k] = raw + s->lead;
+    }
+    const int mbc = s->cfg.mbc;
+    const long st[3] = {1, s->pitch, s->pitch * s->J};
+    const int n[3] = {s->I, s->J, s->K};
+    std::string err;
+    for (int dir = 1; dir <= 3; dir++) {
+        const int d = dir - 1, e = (d + 1) % 3, f = (d + 2) % 3;
+        Unsplit3Launch l;
+        l.a = make_args(s, s->q, s->t1, 1, dt);
+        l.a.dtd = dt / s->cfg.d[d];
+        l.a.dx = s->cfg.d[d];
+        l.a.s_al = st[d]; l.a.n_al = n[d]; l.a.m_al = s->cfg.n[d];
+        l.a.vbc_on = 0;
+        for (int k = 0; k < 14; k++) l.scr[k] = s->scr3[k];
+        l.qacc = s->t1;
+        l.s_e = st[e]; l.s_f = st[f]; l.n_e = n[e]; l.n_f = n[f]; l.m_e = s->cfg.n[e]; l.m_f = s->cfg.n[f];
+        l.m3 = m3; l.m4 = m4;
+        l.dty = dt / s->cfg.d[e]; l.dtz = dt / s->cfg.d[f];
+        l.dir = dir; l.rp = s->cfg.rp; l.stream = s->stream;
+        (void)mbc;
+        pcl_solver::Timed t{};
+        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = dir == 1 ? 0 : 1; t.count = true; hipEventRecord(t.a, s->stream); }
+        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit3(l, err) : pcl::exact::launch_unsplit3(l, err);
+        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
+        if (rc) return fail(rc, err);
+    }
+    return PCL_OK;
+}
+
 // copy the ghost frame (every cell outside the interior) of an nm-plane array
 __global__ void copy_frame_kernel(const double *src, double *dst, int nm, int I, int J, int mbc, long pitch,
                                   long plane) {
@@ -679,6 +723,8 @@ void pcl_destroy(pcl_solver *s) {
         if (p) hipFree(p - s->lead);
     for (double *p : s->scr)
         if (p) hipFree(p - s->lead);
+    for (double *p : s->scr3)
+        if (p) hipFree(p - s->lead);
     for (int k = 1; k < 5; k++)
         if (s->sreg[k]) hipFree(s->sreg[k] - s->lead);
     hipFree(s->cfl_dev);
@@ -901,7 +947,12 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
     if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     HIP_TRY(hipSetDevice(s->cfg.device));
     if (s->cfg.ndim == 3) {  // Godunov splitting x, y, z (clawpack.py:674-690)
-        if (s->cfg.method[2] >= 0) return fail(PCL_EINVAL, "3-D: only dim_split=True (step3ds) is implemented");
+        if (s->cfg.method[2] >= 0) {     // unsplit, clawpack.py:690-696 -> step3.f
+            if (int rc = do_unsplit3(s, dt)) return bail(s, rc);
+            std::swap(s->q, s->t1);
+            s->undo_slot = &s->t1;
+            return read_cfl(s, cfl);
+        }
         if (int rc = do_sweep3(s, s->q, s->t1, 1, dt)) return bail(s, rc);
         if (int rc = do_sweep3(s, s->t1, s->t2, 2, dt)) return bail(s, rc);
         if (int rc = do_sweep3(s, s->t2, s->t3, 3, dt)) return bail(s, rc);
@@ -1204,6 +1255,43 @@ int pcl_debug_wave_shift(const double *in64, double *left64, double *right64) {
 }
 
 // ---- layer 1: f2py-shaped host calls -------------------------------------------------------------
+// The reference's f2py modules are stateless; so are these entry points for the caller.  Inside, the last solver
+// handle is kept and reused while the array shapes stay the same (a time loop calls with identical shapes every
+// step): no hipMalloc / hipFree per call, only the PCIe transfers the host-array interface implies.
+// pcl_layer1_release() frees it (also done when the library is unloaded).
+namespace {
+struct Layer1Cache {
+    pcl_solver *s = nullptr;
+    ~Layer1Cache() { if (s) pcl_destroy(s); }
+};
+Layer1Cache g_l1;
+
+bool same_shape(const pcl_config &a, const pcl_config &b) {
+    return a.ndim == b.ndim && a.n[0] == b.n[0] && a.n[1] == b.n[1] && a.n[2] == b.n[2] && a.mbc == b.mbc &&
+           a.meqn == b.meqn && a.mwaves == b.mwaves && a.maux == b.maux && a.rp == b.rp && a.kind == b.kind &&
+           a.device == b.device && a.math == b.math && a.lim_type == b.lim_type && a.fwave == b.fwave &&
+           a.method[5] == b.method[5] && (a.method[2] < 0) == (b.method[2] < 0);
+}
+// a handle for this configuration: the cached one (its scalars refreshed) or a new one that replaces it
+int layer1_handle(const pcl_config &c, pcl_solver **out) {
+    if (g_l1.s && same_shape(g_l1.s->cfg, c)) {
+        g_l1.s->cfg = c;      // method, mthlim, rp_params, d: read at launch time only
+        g_l1.s->undo_slot = nullptr;
+        g_l1.s->sel = 0;
+        *out = g_l1.s;
+        return PCL_OK;
+    }
+    if (g_l1.s) { pcl_destroy(g_l1.s); g_l1.s = nullptr; }
+    if (int rc = pcl_create(&c, &g_l1.s)) { g_l1.s = nullptr; return rc; }
+    *out = g_l1.s;
+    return PCL_OK;
+}
+}  // namespace
+
+void pcl_layer1_release(void) {
+    if (g_l1.s) { pcl_destroy(g_l1.s); g_l1.s = nullptr; }
+}
+
 static int host_sweep(int ndim, int rp, const double *rp_params, int fwave, int meqn, int mwaves,
                       int maux, int mbc, int mx, int my, const double *qold, double *qnew,
                       const double *aux, double dx, double dy, double dt, const int *method,
@@ -1220,13 +1308,21 @@ static int host_sweep(int ndim, int rp, const double *rp_params, int fwave, int 
     c.fwave = fwave; c.rp = rp;
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
     c.d[0] = dx; c.d[1] = dy; c.device = 0; c.math = PCL_MATH_EXACT;
+    // The Fortran updates qnew IN PLACE (qnew = qnew + increments computed from qold).  Both callers of the reference
+    // pass qnew == qold on entry -- a copy (clawpack.py:529-530,538-541) or the same array (:542-543); the device path
+    // starts from qold, so anything else is refused instead of silently ignored.
+    if (qnew != qold) {
+        const size_t nq = (size_t)meqn * (mx + 2 * mbc) * (ndim > 1 ? my + 2 * mbc : 1);
+        if (memcmp(qold, qnew, nq * sizeof(double)) != 0)
+            return fail(PCL_EINVAL, "qnew must equal qold on entry (a copy or the same array), as in the reference's callers");
+    }
     pcl_solver *s = nullptr;
-    if (int rc = pcl_create(&c, &s)) return rc;
+    if (int rc = layer1_handle(c, &s)) return rc;
     int rc = pcl_put_q(s, qold, 1);
     if (!rc && c.maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
     if (!rc) rc = unsplit ? pcl_step_hyperbolic(s, dt, cfl) : pcl_sweep(s, ids, dt, cfl);
     if (!rc) rc = pcl_get_q(s, qnew, 1);
-    pcl_destroy(s);
+    if (rc) pcl_layer1_release();      // never keep a handle that failed
     return rc;
 }
 
@@ -1276,12 +1372,12 @@ int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux,
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
     c.d[0] = dx; c.d[1] = dy; c.d[2] = dz; c.math = PCL_MATH_EXACT;
     pcl_solver *s = nullptr;
-    if (int rc = pcl_create(&c, &s)) return rc;
+    if (int rc = layer1_handle(c, &s)) return rc;
     int rc = pcl_put_q(s, qold, 1);
     if (!rc && maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
     if (!rc) rc = pcl_sweep(s, idir, dt, cfl);
     if (!rc) rc = pcl_get_q(s, qnew, 1);
-    pcl_destroy(s);
+    if (rc) pcl_layer1_release();
     return rc;
 }
 
@@ -1292,6 +1388,31 @@ int pcl_sharp_module_mthlim(const int *mthlim, int n) {
     if (!mthlim || n < 0 || n > PCL_MAX_WAVES) return fail(PCL_EINVAL, "pcl_sharp_module_mthlim: 0 <= n <= PCL_MAX_WAVES");
     for (int k = 0; k < PCL_MAX_WAVES; k++) g_sharp_mthlim[k] = k < n ? mthlim[k] : 1;
     return PCL_OK;
+}
+
+int pcl_step3(int rp, const double *rp_params, int meqn, int mwaves, int maux, int mbc, int mx, int my, int mz,
+              const double *qold, double *qnew, const double *aux, double dx, double dy, double dz, double dt,
+              const int *method, const int *mthlim, double *cfl) {
+    if (!qold || !qnew || !method || !mthlim || !cfl) return fail(PCL_EINVAL, "null argument");
+    if (method[2] < 0) return fail(PCL_EINVAL, "step3 needs method[2] >= 0 (unsplit)");
+    if (mwaves < 1 || mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
+    pcl_config c;
+    memset(&c, 0, sizeof(c));
+    c.ndim = 3; c.n[0] = mx; c.n[1] = my; c.n[2] = mz; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves;
+    c.maux = maux;
+    for (int k = 0; k < 7; k++) c.method[k] = method[k];
+    for (int k = 0; k < mwaves; k++) c.mthlim[k] = mthlim[k];
+    c.rp = rp;
+    if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
+    c.d[0] = dx; c.d[1] = dy; c.d[2] = dz; c.math = PCL_MATH_EXACT;
+    pcl_solver *s = nullptr;
+    if (int rc = layer1_handle(c, &s)) return rc;
+    int rc = pcl_put_q(s, qold, 1);
+    if (!rc && maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
+    if (!rc) rc = pcl_step_hyperbolic(s, dt, cfl);
+    if (!rc) rc = pcl_get_q(s, qnew, 1);
+    if (rc) pcl_layer1_release();
+    return rc;
 }
 
 static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux,
@@ -1307,13 +1428,14 @@ static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, i
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
     c.d[0] = dx; c.d[1] = dy; c.kind = PCL_KIND_SHARPCLAW; c.lim_type = lim_type; c.math = PCL_MATH_EXACT;
     pcl_solver *s = nullptr;
-    if (int rc = pcl_create(&c, &s)) return rc;
+    if (int rc = layer1_handle(c, &s)) return rc;
     int rc = pcl_put_q(s, q, 1);
     if (!rc && maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
     if (!rc) rc = pcl_sharp_dq(s, dt, cfl);
     if (!rc) rc = pcl_select(s, PCL_REG_DQ);
     if (!rc) rc = pcl_get_q(s, dq, 1);
-    pcl_destroy(s);
+    if (!rc) rc = pcl_select(s, PCL_REG_Q);
+    if (rc) pcl_layer1_release();
     return rc;
 }
 

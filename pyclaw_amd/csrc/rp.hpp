@@ -605,6 +605,66 @@ struct VcAcoustics3D {
     __device__ static __forceinline__ void speeds(const Cell &L, const Cell &R, const RpParams &, double (&s)[2]) {
         s[0] = -L.c; s[1] = R.c;
     }
+    // Transverse solvers of the unsplit algorithm (third-party rpt3_vc_acoustics.f / rptt3_vc_acoustics.f, restated:
+    // oracle/classic_oracle.c).  blk[oe+1][of+1][k]: aux component k (0 = Z, 1 = c) of the cell asdq sits in and of its
+    // neighbours at y-like offset oe / z-like offset of.  icoor = 2 splits in the y-like, 3 in the z-like direction.
+    __device__ static __forceinline__ double pick(const double (&a)[4], int iuvw) {
+        return iuvw == 1 ? a[1] : (iuvw == 2 ? a[2] : a[3]);
+    }
+    template <int DIR>
+    __device__ static __forceinline__ void transverse3(int icoor, const double (&blk)[3][3][2], const double (&asdq)[4],
+                                                       double (&bm)[4], double (&bp)[4]) {
+        int iuvw = DIR + icoor - 1;
+        if (iuvw > 3) iuvw -= 3;
+        double t[4] = {asdq[0], pick(asdq, iuvw), 0.0, 0.0};
+        double om[4], op[4];
+        if (icoor == 2)
+            split3x(blk[0][1][0], blk[1][1][0], blk[2][1][0], blk[0][1][1], blk[2][1][1], t, om, op);
+        else
+            split3x(blk[1][0][0], blk[1][1][0], blk[1][2][0], blk[1][0][1], blk[1][2][1], t, om, op);
+        place(iuvw, om, op, bm, bp);
+    }
+    template <int DIR>
+    __device__ static __forceinline__ void transverse3t(int icoor, int impt, const double (&blk)[3][3][2],
+                                                        const double (&bsasdq)[4], double (&cmo)[4], double (&cpo)[4]) {
+        int iuvw = DIR + icoor - 1;
+        if (iuvw > 3) iuvw -= 3;
+        double t[4] = {bsasdq[0], pick(bsasdq, iuvw), 0.0, 0.0};
+        double om[4], op[4];
+        const int r = impt == 1 ? 0 : 2;
+        if (icoor == 2)       // new split in the y-like direction, inside the z-like row the first split went to
+            split3x(sel(blk, 0, r, 0), sel(blk, 1, r, 0), sel(blk, 2, r, 0), sel(blk, 0, r, 1), sel(blk, 2, r, 1), t, om, op);
+        else                  // new split in the z-like direction, inside the y-like row the first split went to
+            split3x(sel(blk, r, 0, 0), sel(blk, r, 1, 0), sel(blk, r, 2, 0), sel(blk, r, 0, 1), sel(blk, r, 2, 1), t, om, op);
+        place(iuvw, om, op, cmo, cpo);
+    }
+    // blk[a][b][k] with a or b in {0, 2} chosen at run time, written with static indices
+    __device__ static __forceinline__ double sel(const double (&blk)[3][3][2], int a, int b, int k) {
+        double v = 0.0;
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int y = 0; y < 3; y++)
+#pragma unroll
+                for (int z = 0; z < 2; z++)
+                    v = (x == a && y == b && z == k) ? blk[x][y][z] : v;
+        return v;
+    }
+    // t = (asdq(1), asdq(iuvw+1)); om/op = (pressure part, velocity part)
+    __device__ static __forceinline__ void split3x(double zm, double zz, double zp, double cm, double cp,
+                                                   const double (&t)[4], double (&om)[4], double (&op)[4]) {
+        const double a1 = fdiv_ieee(-t[0] + t[1] * zz, zm + zz);
+        const double a2 = fdiv_ieee(t[0] + t[1] * zz, zz + zp);
+        om[0] = cm * a1 * zm; om[1] = -cm * a1; om[2] = om[3] = 0.0;
+        op[0] = cp * a2 * zp; op[1] = cp * a2; op[2] = op[3] = 0.0;
+    }
+    __device__ static __forceinline__ void place(int iuvw, const double (&om)[4], const double (&op)[4],
+                                                 double (&bm)[4], double (&bp)[4]) {
+        bm[0] = om[0]; bp[0] = op[0];
+        bm[1] = iuvw == 1 ? om[1] : 0.0; bp[1] = iuvw == 1 ? op[1] : 0.0;
+        bm[2] = iuvw == 2 ? om[1] : 0.0; bp[2] = iuvw == 2 ? op[1] : 0.0;
+        bm[3] = iuvw == 3 ? om[1] : 0.0; bp[3] = iuvw == 3 ? op[1] : 0.0;
+    }
 };
 
 // ------------------------------------------------------------------------------------

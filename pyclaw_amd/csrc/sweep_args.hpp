@@ -70,6 +70,20 @@ struct CombineArgs {
     int qcor;            // step2qcor.f instead of step2.f (shallow water on the sphere)
 };
 
+// unsplit 3-D (classic3.hpp): one direction's slices into 14 scratch plane sets, then the ordered combine
+struct Unsplit3Launch {
+    SweepArgs a;          // qin = qold; s_al/n_al/m_al, dtd, par, mthlim, order, cfl as for sweep3
+    double *scr[14];
+    double *qacc;         // the new state being accumulated
+    long s_e, s_f;
+    int n_e, n_f, m_e, m_f;
+    int m3, m4;
+    double dty, dtz;
+    int dir;              // 1..3
+    int rp;
+    hipStream_t stream;
+};
+
 struct RkLaunch {
     double *d;
     const double *a, *b, *c;
@@ -96,6 +110,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err);
 bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]);
 int launch_sweep3(const SweepLaunch &l, std::string &err);   // 3-D dim-split sweep, l.ids = direction 1..3
 int launch_slices(const SweepLaunch &l, std::string &err);   // unsplit: per-slice pieces -> scratch
+int launch_unsplit3(const Unsplit3Launch &l, std::string &err);   // unsplit 3-D: slices + combine of one direction
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase
 int launch_sharp(const SweepLaunch &l, std::string &err);     // SharpClaw dq of one direction
@@ -105,6 +120,7 @@ namespace fast {
 int launch_sweep(const SweepLaunch &l, std::string &err);
 int launch_sweep3(const SweepLaunch &l, std::string &err);
 int launch_slices(const SweepLaunch &l, std::string &err);
+int launch_unsplit3(const Unsplit3Launch &l, std::string &err);
 int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase
 int launch_sharp(const SweepLaunch &l, std::string &err);

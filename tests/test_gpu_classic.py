@@ -275,3 +275,36 @@ def test_jump_free_wavefronts_bitexact(coracle, ids, case):
         assert cfl.value == cfl_ref and cfl.value > 0
     if case == "uniform":
         assert np.array_equal(out, q0)
+
+
+def test_layer1_aliased_qnew_and_cached_handle(coracle):
+    """The reference's second step2ds call passes ONE array as qold and qnew (clawpack.py:542-543); the f2py-shaped entry
+    must take that, keep its device buffers between calls of the same shape, and refuse a qnew that differs from qold
+    on entry (the Fortran would add to it; no caller of the reference does that)."""
+    L = _lib()
+    rng = np.random.default_rng(8)
+    mx, my, mbc = 70, 41, 2
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    par = np.array([1.4, 0.4])
+    mth = np.array([4, 4, 4, 4, 2], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 0.7 / my, 0.1 / max(mx, my)
+    q = euler_state(rng, shape)
+    ref = q.copy("F")
+    cfl = C.c_double()
+    for step in range(3):                                   # x sweep (copy), y sweep (aliased), three times
+        qold = ref.copy("F")
+        _, c1 = coracle.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, qold, ref, None, dx, dy, dt, METHOD_DS, mth, 1)
+        _, c2 = coracle.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, ref, ref, None, dx, dy, dt, METHOD_DS, mth, 2)
+        qold = q.copy("F")
+        L.check(L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 0, mbc, mx, my, L.d(qold), L.d(q), None, dx, dy, dt,
+                                    L.i(METHOD_DS), L.i(mth), C.cast(C.byref(cfl), L.dp), 1))
+        assert cfl.value == c1
+        L.check(L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 0, mbc, mx, my, L.d(q), L.d(q), None, dx, dy, dt,
+                                    L.i(METHOD_DS), L.i(mth), C.cast(C.byref(cfl), L.dp), 2))
+        assert cfl.value == c2
+        assert np.array_equal(q, ref), step
+    other = q + 1.0
+    rc = L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 0, mbc, mx, my, L.d(q), L.d(other), None, dx, dy, dt,
+                             L.i(METHOD_DS), L.i(mth), C.cast(C.byref(cfl), L.dp), 1)
+    assert rc == L.EINVAL and b"qnew must equal qold" in L.lib().pcl_last_error()
+    L.lib().pcl_layer1_release()
