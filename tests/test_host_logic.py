@@ -136,7 +136,7 @@ def test_riemann_registry_and_limiter_ids():
     import pyclaw_amd as pyclaw
     from pyclaw_amd import riemann
     ids = [r.id for r in riemann._ALL]
-    assert len(ids) == len(set(ids)) == 13
+    assert len(ids) == len(set(ids)) == 16
     assert riemann.get('rp_euler_5wave_2d') is riemann.rp_euler_5wave_2d and riemann.get('burgers_1d').meqn == 1
     assert riemann.rp_vc_acoustics_2d.has_transverse and riemann.rp_shallow_2d.cparam == ('g',)
     with pytest.raises(Exception):
@@ -170,3 +170,32 @@ def test_clawsolver3d_surface():
     assert s.ndim == 3 and s.dim_split is True and s.order_trans == 22
     assert (s.no_trans, s.trans_inc, s.trans_cor) == (0, 11, 22)
     assert len(s.bc_lower) == 3
+
+
+def test_comm_init_arguments_are_validated_before_rccl():
+    """pcl_comm_check: what pcl_comm_init runs first (host code, no GPU): misuse gets a message, not RCCL's bare
+    "invalid usage" (round-1 record gpurun_out/mgpu.log)."""
+    import numpy as np
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    nb = lambda *v: L.i(np.array(v, dtype=np.int32))
+    free = [-1] * 8
+    assert lib.pcl_comm_check(2, 0, nb(*free)) == 0
+    assert lib.pcl_comm_check(2, 2, nb(*free)) == L.EINVAL and b"rank 2 outside 0..1" in lib.pcl_last_error()
+    assert lib.pcl_comm_check(0, 0, nb(*free)) == L.EINVAL
+    assert lib.pcl_comm_check(4, 1, nb(0, 5, -1, -1, -1, -1, -1, -1)) == L.EINVAL
+    assert b"neighbour E = 5" in lib.pcl_last_error()
+    # a block may be its own neighbour only across a periodic dimension it spans alone: on BOTH faces
+    assert lib.pcl_comm_check(2, 1, nb(0, 0, 1, 1, 0, 0, 0, 0)) == 0          # 2 x 1 blocks, periodic in x and y
+    assert lib.pcl_comm_check(2, 1, nb(0, 0, 1, -1, -1, -1, -1, -1)) == L.EINVAL
+    assert b"S/N" in lib.pcl_last_error()
+
+
+def test_package_control_plane_is_torch_free():
+    """north_star: no PyTorch.  The rendezvous / barrier / host reductions are pyclaw_amd.parallel's own TCP group."""
+    import subprocess
+    import sys
+    code = ("import sys; import pyclaw_amd; from pyclaw_amd import parallel; parallel.init(); "
+            "assert 'torch' not in sys.modules, 'torch imported'; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT if 'ROOT' in globals() else None)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
