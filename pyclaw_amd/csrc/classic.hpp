@@ -76,6 +76,11 @@ template <class RP> __host__ __device__ constexpr bool has_qcor() { return HasQc
 
 // philim.f:19-55
 __device__ __forceinline__ double philim(double a, double b, int meth) {
+#if PCL_FAST
+    // |wave|^2 can underflow (tracer tails): the reciprocal of a denormal is inf and inf*0 a NaN.  By Cauchy-Schwarz
+    // |b| <= sqrt(a_neighbour * a), so with a clamped to 1e-300 the ratio stays finite; such a wave carries nothing.
+    a = __builtin_fmax(a, 1e-300);
+#endif
     const double r = fdiv_ieee(b, a);
     switch (meth) {
     case 1: return dmax(0.0, dmin(1.0, r));
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     // Riemann solvers with cell-wise coefficients (variable-coefficient problems)
     constexpr int NAUX = RP::NAUX, PAUX = MEQN + (CAPA ? 1 : 0);
     constexpr int NP = PAUX + NAUX;
-    __shared__ double tile[NP * T::PLANE];
+    __shared__ __attribute__((aligned(16))) double tile[NP * T::PLANE];
 
     // extents of the swept (along) and transverse (across) directions, ghost cells included
     const int n_along = IXY == 1 ? a.I : a.J;
@@ -451,16 +456,43 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     const int a0 = a.mbc - HALO + ta * (T::NSTRIP * STRIP);
 
     // ---- cooperative load ------------------------------------------------------------------
-    if (IXY == 1) {
+    // Tiles that lie wholly inside the array (all but the last of a row / the last row band) move 16 bytes per lane:
+    // global_load_dwordx4 / global_store_dwordx4, half as many memory instructions and address computations as the
+    // 8-byte form.  Rows start 16-byte aligned (LEAD = 16 - mbc doubles behind a 128-byte aligned base, even tile
+    // offsets), so every pair is aligned; x tiles keep the pair together in LDS (ds_write_b128), y tiles split it
+    // (their LDS rows have the odd pitch 17).
+    const bool full_tile = a0 + T::ALONG <= n_along && b0 >= 0 && b0 + T::ACROSS <= n_across && (a.mbc & 1) == 0;
+    const bool vbc_tile = IXY == 1 && !TRANS && a.vbc_on &&
+                          (a0 < a.mbc || a0 + T::ALONG > n_along - a.mbc || b0 < a.mbc ||
+                           b0 + T::ACROSS > n_across - a.mbc || DIM1);
+    if (IXY == 1 && full_tile && !vbc_tile) {
+        constexpr int PAIRS = T::ALONG / 2, SLOTS = PAIRS * T::ACROSS;      // 122 pairs x 4 rows
+#pragma unroll
+        for (int k = 0; k < (SLOTS + 255) / 256; k++) {
+            const int slot = threadIdx.x + 256 * k;
+            if (slot < SLOTS) {
+                const int ac = slot / PAIRS, al = 2 * (slot % PAIRS);
+                const long g = (long)(b0 + ac) * a.pitch + (a0 + al);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++)
+                    *reinterpret_cast<double2 *>(&tile[T::at(m, al, ac)]) = *reinterpret_cast<const double2 *>(&a.qin[m * a.plane + g]);
+                if constexpr (CAPA)
+                    *reinterpret_cast<double2 *>(&tile[T::at(MEQN, al, ac)]) =
+                        *reinterpret_cast<const double2 *>(&a.aux[(long)(a.mcapa - 1) * a.plane + g]);
+#pragma unroll
+                for (int m = 0; m < NAUX; m++)
+                    *reinterpret_cast<double2 *>(&tile[T::at(PAUX + m, al, ac)]) =
+                        *reinterpret_cast<const double2 *>(&a.aux[aux_idx<RP, IXY>(m) * a.plane + g]);
+            }
+        }
+    } else if (IXY == 1) {
         const int al = threadIdx.x;
         if (al < T::ALONG) {
             int ga = a0 + al;
             ga = ga < n_along ? ga : n_along - 1;  // clamp: cells past the edge repeat the last one
             // only tiles that touch the ghost frame take the remap path (workgroup-uniform): the plain
             // path keeps its 20 loads per thread independent and in flight together
-            const bool vb = !TRANS && a.vbc_on &&
-                            (a0 < a.mbc || a0 + T::ALONG > n_along - a.mbc || b0 < a.mbc ||
-                             b0 + T::ACROSS > n_across - a.mbc || DIM1);
+            const bool vb = vbc_tile;
             if (!vb) {  // one basic block: all 20 loads issue before the first LDS write waits
 #pragma unroll
                 for (int ac = 0; ac < T::ACROSS; ac++) {
@@ -501,6 +533,30 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
                     for (int m = 0; m < NAUX; m++)   // aux ghost cells are real memory (auxbc is filled once at setup)
                         tile[T::at(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + (long)gb * a.pitch + ga];
                 }
+            }
+        }
+    } else if (full_tile) {
+        const int pr = threadIdx.x % (T::ACROSS / 2), ac = 2 * pr;            // 8 pairs per 128-byte row segment
+#pragma unroll
+        for (int k = 0; k < T::ALONG; k += 256 / (T::ACROSS / 2)) {
+            const int al = k + threadIdx.x / (T::ACROSS / 2);
+            const long g = (long)(a0 + al) * a.pitch + (b0 + ac);
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                const double2 v = *reinterpret_cast<const double2 *>(&a.qin[m * a.plane + g]);
+                tile[T::at(m, al, ac)] = v.x;
+                tile[T::at(m, al, ac + 1)] = v.y;
+            }
+            if constexpr (CAPA) {
+                const double2 v = *reinterpret_cast<const double2 *>(&a.aux[(long)(a.mcapa - 1) * a.plane + g]);
+                tile[T::at(MEQN, al, ac)] = v.x;
+                tile[T::at(MEQN, al, ac + 1)] = v.y;
+            }
+#pragma unroll
+            for (int m = 0; m < NAUX; m++) {
+                const double2 v = *reinterpret_cast<const double2 *>(&a.aux[aux_idx<RP, IXY>(m) * a.plane + g]);
+                tile[T::at(PAUX + m, al, ac)] = v.x;
+                tile[T::at(PAUX + m, al, ac + 1)] = v.y;
             }
         }
     } else {
@@ -656,7 +712,27 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[T::at(m, al, ac)];
         }
     };
-    if (IXY == 1) {
+    if (IXY == 1 && full_tile) {
+        constexpr int PAIRS = T::NSTRIP * STRIP / 2, SLOTS = PAIRS * T::ACROSS;   // cells a0+2 .. a0+241: 120 pairs x 4 rows
+#pragma unroll
+        for (int k = 0; k < (SLOTS + 255) / 256; k++) {
+            const int slot = threadIdx.x + 256 * k;
+            if (slot < SLOTS) {
+                const int ac = slot / PAIRS, al = HALO + 2 * (slot % PAIRS);
+                const long g = (long)(b0 + ac) * a.pitch + (a0 + al);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++)
+                    *reinterpret_cast<double2 *>(&a.qout[m * a.plane + g]) = *reinterpret_cast<const double2 *>(&tile[T::at(m, al, ac)]);
+            }
+        }
+        const int t = threadIdx.x;
+        if (t < 2 * HALO) {          // the tile's own halo cells, only where they are ghost cells
+            const int al = t < HALO ? t : T::ALONG - 2 * HALO + t;
+            const int ga = a0 + al;
+            if (ga < a.mbc || ga >= a.mbc + m_along)
+                for (int ac = 0; ac < T::ACROSS; ac++) put(al, ac);
+        }
+    } else if (IXY == 1) {
         const int t = threadIdx.x;
         if (t < T::NSTRIP * STRIP) {  // cells a0+2 .. a0+241: 15 whole lines per row
 #pragma unroll
@@ -667,6 +743,24 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             const int ga = a0 + al;
             if (ga < a.mbc || ga >= a.mbc + m_along)
                 for (int ac = 0; ac < T::ACROSS; ac++) put(al, ac);
+        }
+    } else if (full_tile) {
+        const int pr = threadIdx.x % (T::ACROSS / 2), ac = 2 * pr;
+#pragma unroll
+        for (int k = 0; k < T::ALONG; k += 256 / (T::ACROSS / 2)) {
+            const int al = k + threadIdx.x / (T::ACROSS / 2);
+            const int ga = a0 + al;
+            const bool inner = (ga >= a.mbc) && (ga < a.mbc + m_along);
+            if (inner ? (al >= HALO && al < T::ALONG - HALO) : true) {
+                const long g = (long)ga * a.pitch + (b0 + ac);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) {
+                    double2 v;
+                    v.x = tile[T::at(m, al, ac)];
+                    v.y = tile[T::at(m, al, ac + 1)];
+                    *reinterpret_cast<double2 *>(&a.qout[m * a.plane + g]) = v;
+                }
+            }
         }
     } else {
         const int ac = threadIdx.x % T::ACROSS;
@@ -689,7 +783,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
 // (step2.f:130-137 / :214-218).  Tiles overlap by two slices (U_WAVES/(U_WAVES-2) recompute) instead
 // of moving 8 scratch planes through HBM.
 
-template <class RP, bool FWAVE, int U_WAVES>
+template <class RP, bool FWAVE, int U_WAVES, bool CAPA = false>
 __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, int nstrips) {
     constexpr int MEQN = RP::MEQN;
     constexpr int U_OUT = U_WAVES - 2;
@@ -726,8 +820,23 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, i
             auxa[m] = a.aux[pl + (long)ra * a.pitch + cc];
         }
     }
-    lane_core<RP, 1, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa,
-                                                auxo);
+    // capacity function (step2.f:86-90): dtdx1d = dtdx/capa; every increment is divided by the TARGET cell's capa
+    double capa = 1.0, dtdx_c = a.dtd;
+    if constexpr (CAPA) { capa = a.aux[(long)(a.mcapa - 1) * a.plane + g]; dtdx_c = a.dtd / capa; }
+    lane_core<RP, 1, CAPA, FWAVE, false, true>(q, dtdx_c, capa, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa,
+                                               auxo);
+    // conservation fix on the sphere (step2qcor.f:146-159 + qcor.f): this cell's edge and the next cell's
+    double qc[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) qc[m] = 0.0;
+    if constexpr (has_qcor<RP>() && CAPA) {
+        double er_[6], qc4[4];
+#pragma unroll
+        for (int k = 0; k < 6; k++) er_[k] = from_right(auxv[k]);
+        RP::template qcor<1>(q, auxv, er_, auxv + 6, a.par, qc4);
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) qc[m] = qc4[m];
+    }
 #pragma unroll
     for (int m = 0; m < MEQN; m++) {
         gm[w][m][lane] = a.dtd_t * g1[m];
@@ -739,17 +848,25 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, i
     if (out_row && owned) {
 #pragma unroll
         for (int m = 0; m < MEQN; m++) {
-            double v = q[m] + gp[w - 1][m][lane];                                   // from slice j-1
-            v = v + qadd[m] - a.dtd * df[m] - a.dtd_t * (g2[m] - g1[m]);           // slice j
-            v = v - gm[w + 1][m][lane];                                            // from slice j+1
+            double v;
+            if constexpr (CAPA) {    // step2.f:145-152
+                v = q[m] + gp[w - 1][m][lane] / capa;
+                v = v + qadd[m] - (a.dtd * df[m] + a.dtd_t * (g2[m] - g1[m])) / capa;
+                if constexpr (has_qcor<RP>()) v = v - a.dtd * qc[m] / capa;       // step2qcor.f:157
+                v = v - gm[w + 1][m][lane] / capa;
+            } else {
+                v = q[m] + gp[w - 1][m][lane];                                      // from slice j-1
+                v = v + qadd[m] - a.dtd * df[m] - a.dtd_t * (g2[m] - g1[m]);       // slice j
+                v = v - gm[w + 1][m][lane];                                         // from slice j+1
+            }
             a.qout[m * a.plane + g] = v;
         }
     }
-    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
+    cfl_publish(a.cfl, cfl_value<CAPA>(cflmax, a.dtd));
 }
 
 // y phase: qx = result of the x phase (read and overwritten cell by cell), a.qin = qold
-template <class RP, bool FWAVE, int U_WAVES>
+template <class RP, bool FWAVE, int U_WAVES, bool CAPA = false>
 __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, int ntiles_i, const double *qx) {
     constexpr int MEQN = RP::MEQN;
     constexpr int U_OUT = U_WAVES - 2;
@@ -798,16 +915,66 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
             auxa[m] = a.aux[pl + (long)gj * a.pitch + cn];
         }
     }
-    lane_core<RP, 2, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa,
-                                                auxo);
+    double capa = 1.0, dtdx_c = a.dtd;
+    if constexpr (CAPA) {
+        const int gj = cj < a.J ? cj : a.J - 1;
+        const int c0 = col < a.I ? col : a.I - 1;
+        capa = a.aux[(long)(a.mcapa - 1) * a.plane + (long)gj * a.pitch + c0];
+        dtdx_c = a.dtd / capa;
+        // every wavefront has its qold column in registers: the tile is free to take the x-phase result
+        __syncthreads();
+        const int c = threadIdx.x % U_WAVES, r = threadIdx.x / U_WAVES;
+        int gi = i0 + c, gr = j0 + r;
+        gi = gi < a.I ? gi : a.I - 1;
+        gr = gr < a.J ? gr : a.J - 1;
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) tile[m][r][c] = qx[m * a.plane + (long)gr * a.pitch + gi];
+    }
+    lane_core<RP, 2, CAPA, FWAVE, false, true>(q, dtdx_c, capa, cfl_ok, a, qadd, cflmax, df, g1, g2, auxv, auxb, auxa,
+                                               auxo);
+    double qc[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) qc[m] = 0.0;
+    if constexpr (has_qcor<RP>() && CAPA) {   // step2qcor.f:232-245
+        double er_[6], qc4[4];
+#pragma unroll
+        for (int k = 0; k < 6; k++) er_[k] = from_right(auxv[k]);
+        RP::template qcor<2>(q, auxv, er_, auxv + 6, a.par, qc4);
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) qc[m] = qc4[m];
+    }
 #pragma unroll
     for (int m = 0; m < MEQN; m++) {
         gm[w][m][lane] = a.dtd_t * g1[m];
         gp[w][m][lane] = a.dtd_t * g2[m];
-        tile[m][lane][w] = qadd[m] - a.dtd * df[m] - a.dtd_t * (g2[m] - g1[m]);  // only this wave reads column w
+        if constexpr (!CAPA)
+            tile[m][lane][w] = qadd[m] - a.dtd * df[m] - a.dtd_t * (g2[m] - g1[m]);  // only this wave reads column w
     }
     __syncthreads();
-    {   // cooperative combine + store: q6 = ((q3 + gp'(i-1)) + mid(i)) - gm'(i+1)
+    if constexpr (CAPA) {
+        // step2.f:227-234: each increment divided by this cell's capa, in slice order i-1, i, i+1; the result goes
+        // back into the tile for the coalesced store
+        if (w >= 1 && w <= U_OUT) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                double v = tile[m][lane][w] + gp[w - 1][m][lane] / capa;
+                v = v + qadd[m] - (a.dtd * df[m] + a.dtd_t * (g2[m] - g1[m])) / capa;
+                if constexpr (has_qcor<RP>()) v = v - a.dtd * qc[m] / capa;
+                v = v - gm[w + 1][m][lane] / capa;
+                tile[m][lane][w] = v;
+            }
+        }
+        __syncthreads();
+        const int c = threadIdx.x % U_WAVES, r = threadIdx.x / U_WAVES;
+        const int gi = i0 + c, gj = j0 + r;
+        const bool ok = c >= 1 && c <= U_OUT && gi >= a.mbc && gi < a.mbc + a.mx && r >= HALO && r < WAVE - HALO &&
+                        gj >= a.mbc && gj < a.mbc + a.my;
+        if (ok) {
+            const long g = (long)gj * a.pitch + gi;
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[m][r][c];
+        }
+    } else {   // cooperative combine + store: q6 = ((q3 + gp'(i-1)) + mid(i)) - gm'(i+1)
         const int c = threadIdx.x % U_WAVES, r = threadIdx.x / U_WAVES;
         const int gi = i0 + c, gj = j0 + r;
         const bool ok = c >= 1 && c <= U_OUT && gi >= a.mbc && gi < a.mbc + a.mx && r >= HALO && r < WAVE - HALO &&
@@ -823,7 +990,7 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
             }
         }
     }
-    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
+    cfl_publish(a.cfl, cfl_value<CAPA>(cflmax, a.dtd));
 }
 
 // ---- unsplit algorithm: sum the slice pieces into qnew in the reference's order ----------------

@@ -202,13 +202,21 @@ template <class RP, int UX, int UY> int launch_unsplit_u(const SweepLaunch &l, c
     if (l.ids == 1) {
         const int nstrips = (a.mx + STRIP - 1) / STRIP;
         const int ntr = (a.my + (UX - 2) - 1) / (UX - 2);
-        hipLaunchKernelGGL((unsplit_x_kernel<RP, IsFwave<RP>::value, UX>), dim3((unsigned)nstrips * ntr), dim3(UX * WAVE), 0,
-                           l.stream, a, nstrips);
+        if (a.mcapa > 0)
+            hipLaunchKernelGGL((unsplit_x_kernel<RP, IsFwave<RP>::value, UX, true>), dim3((unsigned)nstrips * ntr),
+                               dim3(UX * WAVE), 0, l.stream, a, nstrips);
+        else
+            hipLaunchKernelGGL((unsplit_x_kernel<RP, IsFwave<RP>::value, UX>), dim3((unsigned)nstrips * ntr),
+                               dim3(UX * WAVE), 0, l.stream, a, nstrips);
     } else {
         const int nti = (a.mx + (UY - 2) - 1) / (UY - 2);
         const int ntj = (a.my + STRIP - 1) / STRIP;
-        hipLaunchKernelGGL((unsplit_y_kernel<RP, IsFwave<RP>::value, UY>), dim3((unsigned)nti * ntj), dim3(UY * WAVE), 0,
-                           l.stream, a, nti, qx);
+        if (a.mcapa > 0)
+            hipLaunchKernelGGL((unsplit_y_kernel<RP, IsFwave<RP>::value, UY, true>), dim3((unsigned)nti * ntj),
+                               dim3(UY * WAVE), 0, l.stream, a, nti, qx);
+        else
+            hipLaunchKernelGGL((unsplit_y_kernel<RP, IsFwave<RP>::value, UY>), dim3((unsigned)nti * ntj),
+                               dim3(UY * WAVE), 0, l.stream, a, nti, qx);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "unsplit launch", e);
@@ -219,7 +227,14 @@ template <class RP> int launch_unsplit_t(const SweepLaunch &l, const double *qx,
     case 1: return launch_unsplit_u<RP, 8, 8>(l, qx, err);
     case 2: return launch_unsplit_u<RP, 16, 8>(l, qx, err);
     case 3: return launch_unsplit_u<RP, 8, 16>(l, qx, err);
-    default: return launch_unsplit_u<RP, 16, 16>(l, qx, err);
+    case 4: return launch_unsplit_u<RP, 12, 12>(l, qx, err);
+    case 5: return launch_unsplit_u<RP, 16, 16>(l, qx, err);
+    default:
+        // 16 wavefronts per workgroup leave 128 VGPRs per lane: enough for the small systems, spills for the Euler
+        // equations (5 components) and the sphere solver (9 + 27 aux values in registers); those take 12 / 8
+        if constexpr (RP::MEQN >= 5) return launch_unsplit_u<RP, 12, 12>(l, qx, err);
+        else if constexpr (RP::NAUX >= 9) return launch_unsplit_u<RP, 8, 8>(l, qx, err);
+        else return launch_unsplit_u<RP, 16, 16>(l, qx, err);
     }
 }
 }  // namespace
@@ -236,6 +251,7 @@ int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
     if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch_unsplit_t<VcAcoustics2D>(l, qx, err);
     if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch_unsplit_t<VcAdvection2D>(l, qx, err);
     if (l.rp == PCL_RP_EULER5_2D) return launch_unsplit_t<Euler5>(l, qx, err);
+    if (l.rp == PCL_RP_SHALLOW_SPHERE_2D) return launch_unsplit_t<ShallowSphere>(l, qx, err);
     err = "Riemann solver id is not a 2-D solver";
     return PCL_EINVAL;
 }

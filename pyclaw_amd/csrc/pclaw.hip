@@ -436,8 +436,8 @@ __global__ void copy_frame_kernel(const double *src, double *dst, int nm, int I,
     }
 }
 
-// unsplit step (step2.f) without a capacity function: x phase q -> t1, y phase updates t1 in place;
-// transverse contributions travel through LDS inside the kernels (classic.hpp), no scratch planes
+// unsplit step (step2.f / step2qcor.f): x phase q -> t1, y phase updates t1 in place; transverse contributions
+// travel through LDS inside the kernels (classic.hpp), no scratch planes
 int do_unsplit_lds(pcl_solver *s, double dt) {
     hipLaunchKernelGGL(copy_frame_kernel, dim3(256), dim3(256), 0, s->stream, s->q, s->t1, s->cfg.meqn, s->I, s->J,
                        s->cfg.mbc, s->pitch, s->plane);
@@ -459,10 +459,11 @@ int do_unsplit_lds(pcl_solver *s, double dt) {
     return PCL_OK;
 }
 
-// unsplit step (step2.f), capacity-function form: x slices and y slices of qold into scratch planes,
-// then one combine pass
+// the scratch-plane form (x slices and y slices of qold into 9-11 planes, then one combine pass): kept as the
+// A/B partner of the LDS kernels, PCL_TUNE_CAPA_SCRATCH=1 selects it for grids with a capacity function
 int do_unsplit(pcl_solver *s, double dt) {
-    if (s->cfg.method[5] == 0) return do_unsplit_lds(s, dt);
+    static const bool scratch = [] { const char *e = getenv("PCL_TUNE_CAPA_SCRATCH"); return e && atoi(e) != 0; }();
+    if (s->cfg.method[5] == 0 || !scratch) return do_unsplit_lds(s, dt);
     const size_t qbytes = ((size_t)s->total + 16) * sizeof(double);
     const bool qcor = s->cfg.rp == PCL_RP_SHALLOW_SPHERE_2D;   // the app's step2qcor.f
     for (int k = 0; k < (qcor ? 11 : 9); k++) {

@@ -36,7 +36,25 @@ __device__ __forceinline__ double dmin(double a, double b) { return __builtin_fm
 // coupled g/h step, two fma residual corrections => correctly rounded), minus the 2^256 input
 // pre-scaling it adds for arguments below 2^-767, which no density/sound-speed ever is.
 // 0, +inf (and NaN / negative => NaN) behave like sqrt().
+// PCL_FAST (rtol 1e-12 mode): one residual correction instead of two (2^-52 instead of correctly rounded).  A negative
+// argument must still give NaN -- the entropy fix relies on "sound speed of an unphysical intermediate state is NaN,
+// every comparison with it is false" (rpn2:217-243) -- so the seed is taken of x itself; only the zero is patched.
+#ifndef PCL_FAST_SQRT          /* (separately switchable for A/B builds) */
+#define PCL_FAST_SQRT PCL_FAST
+#define PCL_FAST_SQRTH PCL_FAST
+#define PCL_FAST_RECIP PCL_FAST
+#endif
 __device__ __forceinline__ double dsqrt(double x) {
+#if PCL_FAST_SQRT
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return x == 0.0 ? 0.0 : g;
+#else
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
     double h = 0.5 * y;
@@ -48,6 +66,7 @@ __device__ __forceinline__ double dsqrt(double x) {
     d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
     return __builtin_amdgcn_class(x, 0x260) ? x : g;  // +-0, +inf pass through
+#endif
 }
 // The same sequence without the +-0 / +inf pass-through (a v_cmp_class and two v_cndmask): for arguments that are
 // strictly positive and finite in every physical state -- a density, the squared Roe sound speed.  (For 0 or inf
@@ -66,8 +85,12 @@ __device__ __forceinline__ SqrtH dsqrt_pos_h(double x) {
     h = __builtin_fma(h, r, h);
     double d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
+#if PCL_FAST_SQRTH
+    return SqrtH{g, h};
+#else
     d = __builtin_fma(-g, g, x);
     return SqrtH{__builtin_fma(d, h, g), h};
+#endif
 }
 __device__ __forceinline__ double dsqrt_pos(double x) { return dsqrt_pos_h(x).g; }
 
@@ -104,8 +127,11 @@ struct Recip {
         double y = __builtin_amdgcn_rcp(den);
         double e = __builtin_fma(-den, y, 1.0);
         y = __builtin_fma(y, e, y);
+#if !PCL_FAST_RECIP   /* fast mode: one Newton step from the 2^-24 seed = 2^-48, plenty for rtol 1e-12 */
         e = __builtin_fma(-den, y, 1.0);
-        r = __builtin_fma(y, e, y);
+        y = __builtin_fma(y, e, y);
+#endif
+        r = y;
     }
     __device__ __forceinline__ double div(double n) const {
 #if PCL_FAST
@@ -123,7 +149,7 @@ __device__ __forceinline__ double fdiv(double n, double d) { return Recip(d).div
 // one division with full IEEE semantics in exact mode (any operands)
 __device__ __forceinline__ double fdiv_ieee(double n, double d) {
 #if PCL_FAST
-    return n * Recip(d).r;
+    return n * Recip(d).r;      // (the limiter clamps a vanishing |wave|^2 first: philim in classic.hpp)
 #else
     return n / d;
 #endif

@@ -143,8 +143,11 @@ template <int IXY> __device__ __forceinline__ int stile_at(int m, int al, int ac
     return IXY == 1 ? (m * T_ACROSS_S + ac) * WAVE + al : (m * WAVE + al) * T_ACROSS_S + (ac ^ ((al >> 1) & 15));
 }
 
+#ifndef PCL_SHARP_OCC
+#define PCL_SHARP_OCC 4     // workgroups per CU the register budget is sized for (A/B: build with -DPCL_SHARP_OCC=3)
+#endif
 template <class RP, int IXY, bool CAPA, int LIM>
-__global__ __launch_bounds__(256, CAPA ? 3 : 4) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
+__global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     constexpr int NAUX = RP::NAUX, PAUX = MEQN + (CAPA ? 1 : 0);   // planes: q, capa, the RP's aux components
     constexpr int NP = PAUX + NAUX;

@@ -26,8 +26,12 @@ def child(args):
     from apps import problems
     n = args.n
     claw = problems.shockbubble(pyclaw, mx=n, my=n, device_callbacks=True, with_src=False,
-                                dt_initial=0.005 * (2.0 / n) / (2.0 / 160.0), run=False, math=args.math[0])
+                                dt_initial=0.005 * (2.0 / n) / (2.0 / 160.0), run=False, math=args.math[0],
+                                dim_split=not args.unsplit)
     solver, solution = claw.solver, claw.solution
+    if args.capa:      # the aux plane (y coordinate) doubles as a smooth capacity function near 1
+        solution.state.aux[0] = 1.0 + 0.2 * solution.state.aux[0]
+        solution.state.mcapa = 0
     if args.state == "random":
         rng = np.random.default_rng(0)
         q = solution.state.q
@@ -62,6 +66,8 @@ def main():
     ap.add_argument("--state", default="bubble")
     ap.add_argument("--math", nargs="+", default=["exact"])
     ap.add_argument("--env", nargs="*", default=[""], help="variants as K=V[,K=V] strings")
+    ap.add_argument("--unsplit", action="store_true", help="step2.f (transverse solves) instead of step2ds.f")
+    ap.add_argument("--capa", action="store_true", help="with a capacity function")
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -77,7 +83,8 @@ def main():
                     env[k] = v
                 out = subprocess.check_output([sys.executable, os.path.abspath(__file__), "--child", "--n", str(args.n),
                                                "--reps", str(args.reps), "--warm", str(args.warm), "--state", args.state,
-                                               "--math", math], env=env)
+                                               "--math", math] + (["--unsplit"] if args.unsplit else []) +
+                                              (["--capa"] if args.capa else []), env=env)
                 d = json.loads(out.decode().strip().splitlines()[-1])
                 res.setdefault((math, var), []).append(d)
     for (math, var), ds in res.items():
