@@ -94,6 +94,16 @@ def developed_state(claw):
     return claw
 
 
+def build_sphere(nx, ny, math, solver_type):
+    """apps/shallow-sphere/shallow_4_Rossby_Haurwitz_wave.py on an nx x ny computational grid (aux and q from the
+    app's own setaux / qinit formulas, apps/shallow_sphere.py)."""
+    import pyclaw_amd as pyclaw
+    from apps import shallow_sphere as ss
+    claw = ss.shallow_sphere(pyclaw, mx=nx, my=ny, run=False, math=math, solver_type=solver_type)
+    claw.solver.dt_initial = 0.1 * 40.0 / nx      # the app's 0.1 at 40x20
+    return claw
+
+
 def build_sharp(nx, ny, math):
     """SharpClaw (WENO5 + SSP104, 10 right-hand sides per step) on the shock-bubble problem."""
     import pyclaw_amd as pyclaw
@@ -224,6 +234,9 @@ def cpu_baseline_all_cores(nx, ny):
     import multiprocessing as mp
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU box's CPU share is 16 cores (the affinity mask shows the whole host); 256 workers x ~1 GB also ran
+    # into the host-memory cap and took 130 s.  PCL_BENCH_CPU_PROCS overrides.
+    cores = max(1, min(cores, int(os.environ.get("PCL_BENCH_CPU_PROCS", "16"))))
     kind = "reference" if O.RefEuler2D.available() else "port"
     sy, nsteps = max(8, min(ny, int(8.0e6 / nx))), 2          # ~3 s per step per core at 5 Mcell/s/core
     ctx = mp.get_context("spawn")                              # no fork of a process that holds a GPU context
@@ -301,6 +314,10 @@ def main():
                     help="also time the fast arithmetic mode (fast_math object)")
     ap.add_argument("--solver", choices=["classic", "sharpclaw"], default="classic",
                     help="sharpclaw: WENO5 + SSP104 on the same problem (single GPU; not the headline)")
+    ap.add_argument("--app", choices=["bubble", "sphere"], default="bubble",
+                    help="sphere: apps/shallow-sphere (Rossby-Haurwitz wave, 16 aux planes, capacity function) on an "
+                         "nx x nx/2 grid, default 2048x1024 = BASELINE configs[4]'s grid; --solver classic is the "
+                         "reference app (unsplit step2qcor + Coriolis source), --solver sharpclaw the configs[4] variant")
     ap.add_argument("--ndim", type=int, default=2, choices=[2, 3],
                     help="3: 3-D dim-split acoustics on an nx^3 grid (single GPU; not the headline)")
     args = ap.parse_args()
@@ -323,6 +340,15 @@ def main():
         pd = parallel.proc_grid([args.nx, args.nx], size) if size > 1 else [1, 1]
         dims, nxg, nyg = [1] + pd, args.nx, args.nx * pd[0]
         claw = build3d((args.nx, args.nx * pd[0], args.nx * pd[1]), args.math)
+    elif args.app == "sphere":
+        if size != 1:
+            sys.stderr.write("bench.py --app sphere runs on one GPU here (the pole boundary mirrors whole rows)\n")
+            sys.exit(2)
+        if args.nx == 4096:
+            args.nx = 2048
+        args.ny = args.nx // 2
+        dims, nxg, nyg = [1, 1], args.nx, args.ny
+        claw = build_sphere(nxg, nyg, args.math, args.solver)
     elif args.solver == "sharpclaw":
         if size != 1:
             sys.stderr.write("bench.py --solver sharpclaw runs on one GPU here\n")
@@ -344,7 +370,7 @@ def main():
 
     cells_total = float(nxg) * float(nyg) * (float(args.nx * dims[2]) if args.ndim == 3 else 1.0)
     value = cells_total * args.steps / elapsed / 1e6
-    headline = args.ndim == 2 and not args.unsplit and args.solver == "classic"
+    headline = args.ndim == 2 and not args.unsplit and args.solver == "classic" and args.app == "bubble"
 
     if rank == 0:
         ns = "pcl::%s::" % args.math
@@ -363,6 +389,18 @@ def main():
             names = [ns + "sharp_kernel<Euler5, 1> (x pass of one RK stage)",
                      ns + "sharp_kernel<Euler5, 2> (y pass + fused RK combination)"]
             per = [80.0, 160.0]
+            bytes_launch = per[dom] * float(args.nx) * float(args.ny)
+        if args.app == "sphere":
+            # every launch reads q (4) and the 16 aux planes and writes q or dq (4); the SharpClaw y pass also reads dq
+            # and the RK operand
+            if args.solver == "sharpclaw":
+                names = [ns + "sharp_kernel<ShallowSphere, 1> (x pass of one RK stage)",
+                         ns + "sharp_kernel<ShallowSphere, 2> (y pass + fused RK combination)"]
+                per = [(4 + 16 + 4) * 8.0, (4 + 16 + 4 + 8) * 8.0]
+            else:
+                names = [ns + "unsplit_x_kernel<ShallowSphere, capa> (x phase)",
+                         ns + "unsplit_y_kernel<ShallowSphere, capa> (y phase)"]
+                per = [(4 + 16 + 4) * 8.0, (4 + 4 + 16 + 4) * 8.0]
             bytes_launch = per[dom] * float(args.nx) * float(args.ny)
         achieved = bytes_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         traffic, traffic_source = pmc_traffic(args.math, dom, args.nx, args.ny) if headline else (None, None)
@@ -396,6 +434,16 @@ def main():
             out["metric"] = "Mcell*steps/s, 2-D Euler SharpClaw WENO5 + SSP104 step (10 right-hand sides per step)"
             out["config"]["workload"] = ("apps/euler 2D shock-bubble, %dx%d cells, SharpClaw lim_type=2 (WENO5), "
                                          "SSP104, source off" % (args.nx, args.ny))
+        if args.app == "sphere":
+            out["metric"] = ("Mcell*steps/s, shallow water on the sphere, %s"
+                             % ("SharpClaw WENO5 + SSP104 step (10 right-hand sides per step)"
+                                if args.solver == "sharpclaw" else
+                                "classic unsplit step2qcor step + Strang-split Coriolis source"))
+            out["config"]["workload"] = (
+                "apps/shallow-sphere Rossby-Haurwitz wave, %dx%d cells, 16 aux planes, capacity function, %s"
+                % (args.nx, args.ny, "SharpClaw lim_type=2 (WENO5), SSP104 (BASELINE configs[4] on one GPU)"
+                   if args.solver == "sharpclaw" else
+                   "classic rpn2/rpt2_shallow_sphere, order_trans=2, MC limiter, src_split=2 (the reference app)"))
         if headline:
             out["config"]["state_note"] = (
                 "headline = shock-bubble initial condition (BASELINE configs[2]): mostly undisturbed gas; wavefronts "
@@ -419,18 +467,23 @@ def main():
                                     "ms_per_step": el4 / 1000 * 1e3, "timed_region_s": el4,
                                     "roofline_frac": bytes_launch / (max(avg4) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "avg_ms": {"x pass": avg4[0], "y pass": avg4[1]}, "result_finite": fin4}
-        if args.extras and size == 1 and headline and args.math == "exact":
-            # the same K steps in the second arithmetic mode (FMA contraction + reciprocal-multiply division;
-            # tests/test_gpu_apps.py holds it to the north-star tolerance rtol 1e-12 on the reference goldens)
-            el2, ms2, nl2, fin2 = timed_run(build(nxg, nyg, "fast", False), args.steps, args.warmup)
-            avg2 = [ms2[k] / max(1, nl2[k]) for k in range(2)]
-            out["fast_math"] = {"value": cells_total * args.steps / el2 / 1e6, "unit": "Mcell*steps/s",
-                                "ms_per_step": el2 / args.steps * 1e3, "parity": "rtol 1e-12 (not bit-identical)",
-                                "roofline_frac": bytes_launch / (max(avg2) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "avg_ms": {"x pass": avg2[0], "y pass": avg2[1]}, "result_finite": fin2}
+        if size == 1 and headline and args.math == "exact" and (args.extras or not args.no_states):
+            # the second arithmetic mode (FMA contraction, reciprocal-multiply division, one-step Newton sqrt;
+            # tests/test_gpu_apps.py holds it to the north-star tolerance rtol 1e-12 on the reference goldens) on the
+            # headline state and on the dense state
+            k3 = args.steps if args.steps <= 300 else 300
+            fm = {"parity": "rtol 1e-12 vs the reference goldens (not bit-identical)"}
+            for tag, mk in (("bubble", lambda c: c), ("dense", dense_state)):
+                el2, ms2, nl2, fin2 = timed_run(mk(build(nxg, nyg, "fast", False)), k3, args.warmup)
+                avg2 = [ms2[k] / max(1, nl2[k]) for k in range(2)]
+                fm[tag] = {"value": cells_total * k3 / el2 / 1e6, "unit": "Mcell*steps/s", "steps": k3,
+                           "ms_per_step": el2 / k3 * 1e3,
+                           "roofline_frac": bytes_launch / (max(avg2) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "avg_ms": {"x pass": avg2[0], "y pass": avg2[1]}, "result_finite": fin2}
+            out["fast_math"] = fm
         if args.ndim == 3:
             out["metric"] = "Mcell*steps/s, 3-D acoustics classic dim-split step (+ achieved HBM GB/s in roofline)"
-        if size == 1 and not args.no_cpu_baseline and args.ndim == 2 and args.solver == "classic":
+        if size == 1 and not args.no_cpu_baseline and args.ndim == 2 and args.solver == "classic" and args.app == "bubble":
             try:
                 out["cpu_baseline"] = cpu_baseline(args.nx, args.ny)
             except Exception as e:      # the oracle is optional infrastructure, never the product

@@ -230,10 +230,10 @@ template <class RP> int launch_unsplit_t(const SweepLaunch &l, const double *qx,
     case 4: return launch_unsplit_u<RP, 12, 12>(l, qx, err);
     case 5: return launch_unsplit_u<RP, 16, 16>(l, qx, err);
     default:
-        // 16 wavefronts per workgroup leave 128 VGPRs per lane: enough for the small systems, spills for the Euler
-        // equations (5 components) and the sphere solver (9 + 27 aux values in registers); those take 12 / 8
-        if constexpr (RP::MEQN >= 5) return launch_unsplit_u<RP, 12, 12>(l, qx, err);
-        else if constexpr (RP::NAUX >= 9) return launch_unsplit_u<RP, 8, 8>(l, qx, err);
+        // 16 wavefronts per workgroup leave 128 VGPRs per lane: the Euler kernels spill ~20 registers there and are
+        // still 4 % faster than with 12 wavefronts (170 VGPRs, no spills; profiles/r02_kernel_ab_and_ubench.txt); the
+        // sphere solver (9 + 27 aux values per lane) takes 8
+        if constexpr (RP::NAUX >= 9) return launch_unsplit_u<RP, 8, 8>(l, qx, err);
         else return launch_unsplit_u<RP, 16, 16>(l, qx, err);
     }
 }

@@ -450,7 +450,7 @@ int do_unsplit_lds(pcl_solver *s, double dt) {
         l.a.dtd_t = dt / s->cfg.d[2 - ids];
         l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = s->stream;
         pcl_solver::Timed t{};
-        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; hipEventRecord(t.a, s->stream); }
+        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = true; hipEventRecord(t.a, s->stream); }
         int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit(l, s->t1, err)
                                               : pcl::exact::launch_unsplit(l, s->t1, err);
         if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
@@ -489,7 +489,7 @@ int do_unsplit(pcl_solver *s, double dt) {
         }
         l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = s->stream;
         pcl_solver::Timed t{};
-        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; hipEventRecord(t.a, s->stream); }
+        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = true; hipEventRecord(t.a, s->stream); }
         int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_slices(l, err) : pcl::exact::launch_slices(l, err);
         if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
         if (rc) return fail(rc, err);
