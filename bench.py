@@ -154,7 +154,7 @@ def build3d(n, math):
 PMC_FILE = "r02_pmc_hbm.json"     # written by tools/profile_round.sh (falls back to the round-1 file)
 
 
-def pmc_traffic(math, which, nx, ny):
+def pmc_traffic(math, which, nx, ny, state="bubble"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/<round>_pmc_hbm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
     passes, same bench command).  PMC counters cannot be read from inside this process, so the
@@ -167,8 +167,9 @@ def pmc_traffic(math, which, nx, ny):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 doc = json.load(f)
-            for name, v in doc["modes"][math].items():
-                if ("Euler5, %d," % (which + 1)) in name:
+            key = math if state == "bubble" else "%s_%s" % (math, state)
+            for name, v in doc["modes"][key].items():
+                if "sweep_kernel" in name and ("Euler5, %d," % (which + 1)) in name:
                     return v["hbm_bytes_per_launch_corrected"], (
                         "from committed profile profiles/%s (collected at commit %s)" % (fn, doc.get("commit", "round-1 HEAD")))
         except Exception:
@@ -308,6 +309,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-states", action="store_true",
                     help="skip the dense_state / developed_state / sustained objects of the default line")
+    ap.add_argument("--state", choices=["bubble", "dense", "developed"], default="bubble",
+                    help="state the main timed run starts from (profile runs of the dense / developed state: "
+                         "tools/profile_round.sh); anything but bubble implies --no-states")
     ap.add_argument("--math", choices=["exact", "fast"], default="exact")
     ap.add_argument("--unsplit", action="store_true", help="unsplit algorithm with order_trans=2 (not the headline)")
     ap.add_argument("--extras", action="store_true",
@@ -366,6 +370,12 @@ def main():
         dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
         nxg, nyg = args.nx * dims[0], args.ny * dims[1]
         claw = build(nxg, nyg, args.math, args.unsplit)
+    if args.state != "bubble":
+        if args.ndim != 2 or args.solver != "classic" or args.app != "bubble" or size != 1:
+            sys.stderr.write("bench.py --state applies to the 2-D Euler classic step on one GPU\n")
+            sys.exit(2)
+        claw = dense_state(claw) if args.state == "dense" else developed_state(claw)
+        args.no_states = True
     elapsed, ms, nl, finite = timed_run(claw, args.steps, args.warmup)
 
     cells_total = float(nxg) * float(nyg) * (float(args.nx * dims[2]) if args.ndim == 3 else 1.0)
@@ -403,7 +413,8 @@ def main():
                 per = [(4 + 16 + 4) * 8.0, (4 + 4 + 16 + 4) * 8.0]
             bytes_launch = per[dom] * float(args.nx) * float(args.ny)
         achieved = bytes_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
-        traffic, traffic_source = pmc_traffic(args.math, dom, args.nx, args.ny) if headline else (None, None)
+        traffic, traffic_source = (pmc_traffic(args.math, dom, args.nx, args.ny, args.state) if headline
+                                   else (None, None))
         if scaling == "strong":
             grid_note = ("GLOBAL grid %dx%d fixed (strong scaling), %dx%d blocks, %dx%d cells on rank 0"
                          % (nxg, nyg, dims[0], dims[1], args.nx, args.ny))
@@ -444,7 +455,9 @@ def main():
                 % (args.nx, args.ny, "SharpClaw lim_type=2 (WENO5), SSP104 (BASELINE configs[4] on one GPU)"
                    if args.solver == "sharpclaw" else
                    "classic rpn2/rpt2_shallow_sphere, order_trans=2, MC limiter, src_split=2 (the reference app)"))
-        if headline:
+        if args.state != "bubble":
+            out["config"]["workload"] += "; STATE: %s (not the shock-bubble initial condition)" % args.state
+        elif headline:
             out["config"]["state_note"] = (
                 "headline = shock-bubble initial condition (BASELINE configs[2]): mostly undisturbed gas; wavefronts "
                 "without a jump take an exact shortcut and absent wave families skip the limiter (bit-identical "

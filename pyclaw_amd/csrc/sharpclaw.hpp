@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
     __syncthreads();
 
     // cooperative store of dq for the owned interior cells
+    // dq/6 of the SSP33 / Euler-substage combination (op 1): one shared reciprocal, correctly rounded quotients
+    // (rp.hpp Recip; dq is a normal-range quantity or exactly zero) instead of 20 IEEE divisions per thread
+    const Recip by_ca(a.rk_op == 1 ? a.rk_ca : 1.0);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
                 double r = dq;
                 if (a.rk_op != 0) {
                     const double av = a.rk_a[at], bv = a.rk_b[at];
-                    const double r1 = av + dq / a.rk_ca;
+                    const double r1 = av + by_ca.div(dq);
                     const double r2 = a.rk_ca * av + a.rk_cb * (bv + dq);
                     const double r5 = av + a.rk_cb * bv + a.rk_cc * dq;
                     r = a.rk_op == 1 ? r1 : (a.rk_op == 2 ? r2 : r5);

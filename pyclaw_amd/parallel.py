@@ -339,6 +339,10 @@ def decompose(grid):
     existing = getattr(grid, "_decomp", None)
     if existing is not None:
         return existing
+    if len(grid.n) == 1:
+        # a 1-D grid is a single row of cells: every rank keeps the whole row (replicas); the device halo exchange
+        # (pcl_comm_init) serves 2-D blocks and 3-D blocks cut in (y, z)
+        return None
     dec = Decomposition(grid.n, world_size(), rank())
     for k, dim in enumerate(grid.dimensions):
         dim._set_range(*dec.ranges[k])
