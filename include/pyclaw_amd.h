@@ -268,6 +268,15 @@ int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl);
 int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, double ca, double cb, double cc,
                     double cfl_max, double *cfl);
 
+/* pcl_sharp_dq / pcl_sharp_stage preceded by the stage's apply_q_bcs (sharpclaw.py:347, solver.py:354-381) in the
+ * same call: halo exchange of the selected register in a decomposed run, then the physical BCs (`bc`, `cstate` as
+ * for pcl_bc_step: 2*ndim types, <0 = no fill on that side, PCL_BC_CUSTOM = constant state).  In a decomposed 2-D
+ * run the ghost frame is built on the halo stream while the x pass runs the tiles that read no ghost cell
+ * (PCL_HALO_OVERLAP=0 keeps everything on one stream). */
+int pcl_sharp_bc_dq(pcl_solver *s, const int *bc, const double *cstate, double dt, double *cfl);
+int pcl_sharp_bc_stage(pcl_solver *s, const int *bc, const double *cstate, double dt, int op, int D, int A, int B,
+                       double ca, double cb, double cc, double cfl_max, double *cfl);
+
 /* Register arithmetic of the Runge-Kutta schemes (sharpclaw.py:168-206), evaluated in the order
  * written: op 1: D = A + B/ca   2: D = ca*A + cb*(B + C)   3: D = A/ca + cb*B
  *          4: D = ca*A - cb*B   5: D = A + cb*B + cc*C

@@ -87,6 +87,9 @@ PROTOTYPES = {
     "pcl_sharp_dq": (C.c_int, [C.c_void_p, C.c_double, dp]),
     "pcl_sharp_stage": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                   C.c_double, C.c_double, dp]),
+    "pcl_sharp_bc_dq": (C.c_int, [C.c_void_p, ip, dp, C.c_double, dp]),
+    "pcl_sharp_bc_stage": (C.c_int, [C.c_void_p, ip, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                     C.c_double, C.c_double, C.c_double, dp]),
     "pcl_rk_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                             C.c_double]),
     "pcl_sync": (C.c_int, [C.c_void_p]),

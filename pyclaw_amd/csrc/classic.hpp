@@ -405,7 +405,7 @@ __device__ __forceinline__ int xcd_logical_block(int on) {
     return x * base + (x < rem ? x : rem) + k;
 }
 
-template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = false>
+template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1>
 __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     using T = TileShape<IXY>;
     constexpr int MEQN = RP::MEQN;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     // are line-aligned and share almost nothing)
     int tb = IXY == 1 ? blockIdx.x / ntiles_along : blockIdx.x % ntiles_across;
     int ta = IXY == 1 ? blockIdx.x % ntiles_along : blockIdx.x / ntiles_across;
-    if (IXY == 1 && !DIM1 && !TRANS && a.sub != 0) {  // workgroup-uniform: interior box / its complement
+    if (IXY == 1 && !DIM1 && a.sub != 0) {  // workgroup-uniform: interior box / its complement
         int idx = blockIdx.x;
         const int bw = a.box[3] - a.box[2];
         if (a.sub == 1) {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     // offsets), so every pair is aligned; x tiles keep the pair together in LDS (ds_write_b128), y tiles split it
     // (their LDS rows have the odd pitch 17).
     const bool full_tile = a0 + T::ALONG <= n_along && b0 >= 0 && b0 + T::ACROSS <= n_across && (a.mbc & 1) == 0;
-    const bool vbc_tile = IXY == 1 && !TRANS && a.vbc_on &&
+    const bool vbc_tile = IXY == 1 && a.vbc_on &&
                           (a0 < a.mbc || a0 + T::ALONG > n_along - a.mbc || b0 < a.mbc ||
                            b0 + T::ACROSS > n_across - a.mbc || DIM1);
     if (IXY == 1 && full_tile && !vbc_tile) {
@@ -588,10 +588,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     auto unit_al = [&](int u) { return (IXY == 1 ? u * STRIP : 0) + lane; };
     auto unit_live = [&](int u) {  // wave-uniform
         const int gb = b0 + unit_ac(u);
-        // step2ds sweeps every transverse index (ghost rows too, step2ds.f:83-88); the unsplit
-        // step2 only slices 0..m+1, i.e. one ghost layer (step2.f:84,164)
-        const int m_across = IXY == 1 ? a.my : a.mx;
-        const bool across_ok = TRANS ? (gb >= a.mbc - 1 && gb <= a.mbc + m_across) : (gb >= 0 && gb < n_across);
+        // step2ds sweeps every transverse index, ghost rows too (step2ds.f:83-88)
+        const bool across_ok = gb >= 0 && gb < n_across;
         const bool along_ok = a0 + (IXY == 1 ? u * STRIP : 0) + HALO < a.mbc + m_along;  // not all past the interior
         return u < T::UNITS && across_ok && along_ok;
     };
@@ -625,81 +623,15 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
         double auxv[NAUX > 0 ? NAUX : 1];
 #pragma unroll
         for (int m = 0; m < NAUX; m++) auxv[m] = tile[T::at(PAUX + m, al, ac)];   // aux planes are never overwritten
-        if constexpr (TRANS) {
-            // unsplit algorithm: this slice's pieces for the cell go to scratch planes; they are
-            // summed into qnew in the reference's order by combine_kernel (step2.f:130-137,214-218)
-            double df[MEQN], g1[MEQN], g2[MEQN];
-            // transverse solvers with cell-wise coefficients: their aux set of the cell itself and of the cells in
-            // the slices below / above
-            constexpr int NT = naux_t<RP>() > 0 ? naux_t<RP>() : 1;
-            double auxo[NT], auxb[NT], auxa[NT];
-            if constexpr (NAUX > 0) {
-                const int gbc = b0 + ac < n_across ? b0 + ac : n_across - 1;
-                const int gbb = gbc > 0 ? gbc - 1 : 0, gba = gbc + 1 < n_across ? gbc + 1 : n_across - 1;
-                const int cac = ca < n_along ? ca : n_along - 1;
+        if (a.ablate & 1) {
 #pragma unroll
-                for (int m = 0; m < NT; m++) {
-                    const long pl = auxt_idx<RP, IXY>(m) * a.plane;
-                    auxo[m] = a.aux[pl + (IXY == 1 ? (long)gbc * a.pitch + cac : (long)cac * a.pitch + gbc)];
-                    auxb[m] = a.aux[pl + (IXY == 1 ? (long)gbb * a.pitch + cac : (long)cac * a.pitch + gbb)];
-                    auxa[m] = a.aux[pl + (IXY == 1 ? (long)gba * a.pitch + cac : (long)cac * a.pitch + gba)];
-                }
-            }
-            lane_core<RP, IXY, CAPA, FWAVE, DIM1, true>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, df, g1, g2, auxv, auxb,
-                                                        auxa, auxo);
-            // conservation fix on the sphere (step2qcor.f:146-159,232-245 + qcor.f): the cell's own edge and the
-            // next cell's edge along the sweep, both still in the LDS tile
-            double qc[MEQN];
+            for (int m = 0; m < MEQN; m++) qn[m] = q[m];
+        } else
+            lane_core<RP, IXY, CAPA, FWAVE, DIM1>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, nullptr, nullptr, nullptr, auxv);
+        if (owned) {
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) qc[m] = 0.0;
-            if constexpr (has_qcor<RP>() && CAPA) {
-                double er_[6];
-                const int aln = al + 1 < T::ALONG ? al + 1 : al;
-#pragma unroll
-                for (int k = 0; k < 6; k++) er_[k] = tile[T::at(PAUX + k, aln, ac)];
-                double qc4[4];
-                RP::template qcor<IXY>(q, auxv, er_, auxv + 6, a.par, qc4);
-#pragma unroll
-                for (int m = 0; m < MEQN; m++) qc[m] = qc4[m];
-            }
-            if (owned) {
-                const int gb = b0 + ac;
-                const long g = IXY == 1 ? (long)gb * a.pitch + ca : (long)ca * a.pitch + gb;
-#pragma unroll
-                for (int m = 0; m < MEQN; m++) {
-                    const long at = m * a.plane + g;
-                    const double fl = a.dtd * df[m];          // dtdx*(fadd(i+1)-fadd(i))
-                    const double gl = a.dtd_t * (g2[m] - g1[m]);  // dtdy*(gadd(2)-gadd(1))
-                    if (CAPA) {          // step2.f:145-148,227-230: qadd and (fl+gl), divided by capa later
-                        a.scr[0][at] = qn[m];
-                        a.scr[1][at] = fl + gl;
-                    } else if (IXY == 1) {  // step2.f:132-134: ((qnew+qadd) - fl) - gl
-                        a.scr[0][at] = qn[m];
-                        a.scr[1][at] = fl;
-                        a.scr[2][at] = gl;
-                    } else {               // step2.f:214-216: qnew + (qadd - fl - gl)
-                        a.scr[0][at] = qn[m] - fl - gl;
-                    }
-                    a.scr[3][at] = a.dtd_t * g1[m];
-                    a.scr[4][at] = a.dtd_t * g2[m];
-                    if constexpr (has_qcor<RP>() && CAPA) a.scr[5][at] = a.dtd * qc[m];
-                }
-            }
-        } else {
-            if (a.ablate & 1) {
-#pragma unroll
-                for (int m = 0; m < MEQN; m++) qn[m] = q[m];
-            } else
-                lane_core<RP, IXY, CAPA, FWAVE, DIM1>(q, dtdx_c, capa, cfl_ok, a, qn, cflmax, nullptr, nullptr, nullptr, auxv);
-            if (owned) {
-#pragma unroll
-                for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = qn[m];
-            }
+            for (int m = 0; m < MEQN; m++) tile[T::at(m, al, ac)] = qn[m];
         }
-    }
-    if constexpr (TRANS) {
-        cfl_publish(a.cfl, cfl_value<CAPA>(cflmax, a.dtd));
-        return;
     }
     __syncthreads();
 
@@ -792,6 +724,10 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, i
     const int w = threadIdx.x / WAVE;
     const int bid = xcd_logical_block(a.xcd);
     const int ta = bid % nstrips, tr = bid / nstrips;
+    if (a.sub != 0) {   // decomposed run: the tiles that read no ghost cell (box) in one launch, the rim in another
+        const bool inside = tr >= a.box[0] && tr < a.box[1] && ta >= a.box[2] && ta < a.box[3];
+        if ((a.sub == 1) != inside) return;             // workgroup-uniform, before any barrier
+    }
     const int a0 = a.mbc - HALO + ta * STRIP;
     const int row = a.mbc - 1 + tr * U_OUT + w;        // slices j = 0 .. my+1  <->  rows mbc-1 .. mbc+my
     const bool slice_ok = row <= a.mbc + a.my;           // wave-uniform
@@ -991,50 +927,6 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
         }
     }
     cfl_publish(a.cfl, cfl_value<CAPA>(cflmax, a.dtd));
-}
-
-// ---- unsplit algorithm: sum the slice pieces into qnew in the reference's order ----------------
-// step2.f runs the x slices j = 0..my+1 in ascending order, each adding into rows j-1, j, j+1,
-// then the y slices i = 0..mx+1 adding into columns i-1, i, i+1.  For interior cell (i,j) that is
-//   q1 = q0 + dtdy*gadd2 [slice j-1]            q4 = q3 + dtdx*gadd2 [slice i-1]
-//   q2 = ((q1 + qadd) - dtdx*df) - dtdy*dg [j]  q5 = q4 + (qadd - dtdy*df - dtdx*dg) [slice i]
-//   q3 = q2 - dtdy*gadd1 [slice j+1]            q6 = q5 - dtdx*gadd1 [slice i+1]
-// (with a capacity function every increment is divided by capa of the TARGET cell and the two
-// flux-difference terms are summed first, step2.f:145-152,227-234).  One thread per cell.
-template <bool CAPA, bool QCOR = false>
-__global__ __launch_bounds__(256) void combine_kernel(CombineArgs c) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (i >= c.I) return;
-    const long g = (long)j * c.pitch + i;
-    if (i < c.mbc || i >= c.mbc + c.mx || j < c.mbc || j >= c.mbc + c.my) {  // ghost cells: unchanged
-        for (int m = 0; m < c.meqn; m++) c.qnew[m * c.plane + g] = c.qold[m * c.plane + g];
-        return;
-    }
-    double capa = 1.0;
-    if (CAPA) capa = c.aux[(long)(c.mcapa - 1) * c.plane + g];
-    for (int m = 0; m < c.meqn; m++) {
-        const long at = m * c.plane + g;
-        double q = c.qold[at];
-        if (CAPA) {
-            q = q + c.x[4][at - c.pitch] / capa;
-            q = q + c.x[0][at] - c.x[1][at] / capa;
-            if (QCOR) q = q - c.x[5][at] / capa;          // step2qcor.f:157: right after the cell's own x update
-            q = q - c.x[3][at + c.pitch] / capa;
-            q = q + c.y[3][at - 1] / capa;
-            q = q + c.y[0][at] - c.y[1][at] / capa;
-            if (QCOR) q = q - c.y[4][at] / capa;          // step2qcor.f:243
-            q = q - c.y[2][at + 1] / capa;
-        } else {
-            q = q + c.x[4][at - c.pitch];
-            q = q + c.x[0][at] - c.x[1][at] - c.x[2][at];
-            q = q - c.x[3][at + c.pitch];
-            q = q + c.y[3][at - 1];
-            q = q + c.y[0][at];
-            q = q - c.y[2][at + 1];
-        }
-        c.qnew[at] = q;
-    }
 }
 
 // ---- 3-D dimension-split sweep (step3ds.f:108-374 + flux3.f:168-258) ---------------------------------

@@ -24,7 +24,7 @@ int hip_fail(std::string &err, const char *what, hipError_t e) {
     return PCL_EHIP;
 }
 
-template <class RP, int IXY, bool DIM1, bool TRANS = false> int launch(const SweepLaunch &l, std::string &err) {
+template <class RP, int IXY, bool DIM1> int launch(const SweepLaunch &l, std::string &err) {
     using T = TileShape<IXY>;
     const SweepArgs &a = l.a;
     const int n_across = IXY == 1 ? a.J : a.I + (LINE - a.mbc);  // y: columns counted from the line boundary
@@ -33,7 +33,7 @@ template <class RP, int IXY, bool DIM1, bool TRANS = false> int launch(const Swe
     const int ntiles_along = (m_along + T::NSTRIP * STRIP - 1) / (T::NSTRIP * STRIP);
     unsigned nblocks = (unsigned)ntiles_across * (unsigned)ntiles_along;
     if (a.sub != 0) {
-        if (IXY != 1 || DIM1 || TRANS || a.box[0] < 0 || a.box[1] > ntiles_across || a.box[2] < 0 ||
+        if (IXY != 1 || DIM1 || a.box[0] < 0 || a.box[1] > ntiles_across || a.box[2] < 0 ||
             a.box[3] > ntiles_along || a.box[0] >= a.box[1] || a.box[2] >= a.box[3]) {
             err = "tile subset: bad box";
             return PCL_EINVAL;
@@ -50,10 +50,10 @@ template <class RP, int IXY, bool DIM1, bool TRANS = false> int launch(const Swe
         return PCL_EINVAL;
     }
     if (a.mcapa > 0)
-        hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, FW, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
+        hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, FW, DIM1>), grid, dim3(256), 0, l.stream, a,
                            ntiles_across, ntiles_along);
     else
-        hipLaunchKernelGGL((sweep_kernel<RP, IXY, false, FW, DIM1, TRANS>), grid, dim3(256), 0, l.stream, a,
+        hipLaunchKernelGGL((sweep_kernel<RP, IXY, false, FW, DIM1>), grid, dim3(256), 0, l.stream, a,
                            ntiles_across, ntiles_along);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep launch", e);
@@ -169,39 +169,21 @@ bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]) {
 }
 #endif
 
-// unsplit (step2.f): per-slice pieces of one direction into the scratch planes
-int launch_slices(const SweepLaunch &l, std::string &err) {
-    if (l.ndim != 2) { err = "step2 is 2-D"; return PCL_EINVAL; }
-    if (l.ids == 1) {
-        if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 1, false, true>(l, err);
-        if (l.rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 1, false, true>(l, err);
-        if (l.rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 1, false, true>(l, err);
-        if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 1, false, true>(l, err);
-        if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 1, false, true>(l, err);
-        if (l.rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 1, false, true>(l, err);
-        if (l.rp == PCL_RP_PSYSTEM_FWAVE_2D) return launch<PSystem2D, 1, false, true>(l, err);
-        if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 1, false, true>(l, err);
-    } else {
-        if (l.rp == PCL_RP_ACOUSTICS_2D) return launch<Acoustics2D, 2, false, true>(l, err);
-        if (l.rp == PCL_RP_ADVECTION_2D) return launch<Advection2D, 2, false, true>(l, err);
-        if (l.rp == PCL_RP_SHALLOW_2D) return launch<Shallow2D, 2, false, true>(l, err);
-        if (l.rp == PCL_RP_VC_ACOUSTICS_2D) return launch<VcAcoustics2D, 2, false, true>(l, err);
-        if (l.rp == PCL_RP_VC_ADVECTION_2D) return launch<VcAdvection2D, 2, false, true>(l, err);
-        if (l.rp == PCL_RP_SHALLOW_SPHERE_2D) return launch<ShallowSphere, 2, false, true>(l, err);
-        if (l.rp == PCL_RP_PSYSTEM_FWAVE_2D) return launch<PSystem2D, 2, false, true>(l, err);
-        if (l.rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false, true>(l, err);
-    }
-    err = "Riemann solver id is not a 2-D solver";
-    return PCL_EINVAL;
-}
-
-// unsplit, no capacity function: both phases without scratch planes (classic.hpp: unsplit_x/y_kernel)
+// unsplit step (step2.f / step2qcor.f): both phases without scratch planes (classic.hpp: unsplit_x/y_kernel)
 namespace {
 template <class RP, int UX, int UY> int launch_unsplit_u(const SweepLaunch &l, const double *qx, std::string &err) {
-    const SweepArgs &a = l.a;
+    SweepArgs a = l.a;
     if (l.ids == 1) {
         const int nstrips = (a.mx + STRIP - 1) / STRIP;
         const int ntr = (a.my + (UX - 2) - 1) / (UX - 2);
+        if (a.sub != 0) {
+            // tiles whose 64 cells x UX rows lie inside the interior: cells mbc-2+60*ta .. +63 within [mbc, mbc+mx),
+            // rows mbc-1+(UX-2)*tr .. +UX-1 within [mbc, mbc+my)
+            a.box[0] = 1;
+            a.box[1] = a.my - UX + 1 >= 0 ? (a.my - UX + 1) / (UX - 2) + 1 : 0;
+            a.box[2] = 1;
+            a.box[3] = a.mx >= 62 ? (a.mx - 62) / STRIP + 1 : 0;
+        }
         if (a.mcapa > 0)
             hipLaunchKernelGGL((unsplit_x_kernel<RP, IsFwave<RP>::value, UX, true>), dim3((unsigned)nstrips * ntr),
                                dim3(UX * WAVE), 0, l.stream, a, nstrips);
@@ -230,11 +212,15 @@ template <class RP> int launch_unsplit_t(const SweepLaunch &l, const double *qx,
     case 4: return launch_unsplit_u<RP, 12, 12>(l, qx, err);
     case 5: return launch_unsplit_u<RP, 16, 16>(l, qx, err);
     default:
-        // 16 wavefronts per workgroup leave 128 VGPRs per lane: the Euler kernels spill ~20 registers there and are
-        // still 4 % faster than with 12 wavefronts (170 VGPRs, no spills; profiles/r02_kernel_ab_and_ubench.txt); the
-        // sphere solver (9 + 27 aux values per lane) takes 8
+        // 16 wavefronts per workgroup leave 128 VGPRs per lane.  The Euler kernels spill ~20 registers there and are
+        // still 4 % faster than with 12 wavefronts (170 VGPRs, no spills) -- except with a capacity function, where the
+        // spill stores reach HBM (2.4 GB written per x launch at 4096^2 for 0.67 GB of results,
+        // profiles/r02_pmc_hbm.json) at equal speed: 12 there.  The sphere solver (9 + 27 aux values per lane) takes 8.
         if constexpr (RP::NAUX >= 9) return launch_unsplit_u<RP, 8, 8>(l, qx, err);
-        else return launch_unsplit_u<RP, 16, 16>(l, qx, err);
+        else if constexpr (RP::MEQN >= 5) {
+            if (l.a.mcapa > 0) return launch_unsplit_u<RP, 12, 12>(l, qx, err);
+            return launch_unsplit_u<RP, 16, 16>(l, qx, err);
+        } else return launch_unsplit_u<RP, 16, 16>(l, qx, err);
     }
 }
 }  // namespace
@@ -256,22 +242,18 @@ int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
     return PCL_EINVAL;
 }
 
-int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err) {
-    const dim3 grid((unsigned)((c.I + 255) / 256), (unsigned)c.J);
-    if (c.mcapa > 0 && c.qcor)
-        hipLaunchKernelGGL((combine_kernel<true, true>), grid, dim3(256), 0, stream, c);
-    else if (c.mcapa > 0)
-        hipLaunchKernelGGL(combine_kernel<true>, grid, dim3(256), 0, stream, c);
-    else
-        hipLaunchKernelGGL(combine_kernel<false>, grid, dim3(256), 0, stream, c);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? PCL_OK : hip_fail(err, "combine launch", e);
-}
-
 // SharpClaw: dq of one direction (x writes dq, y accumulates)
 namespace {
 template <class RP, int IXY> int launch_sharp_t(const SweepLaunch &l, std::string &err) {
-    const SweepArgs &a = l.a;
+    SweepArgs a = l.a;
+    if (IXY == 1 && a.sub != 0) {
+        // x-pass tiles whose 16 rows x 64 cells lie inside the interior: rows 16*tb .. +15 within [mbc, mbc+my), cells
+        // mbc-3+58*ta .. +63 within [mbc, mbc+mx)
+        a.box[0] = (a.mbc + T_ACROSS_S - 1) / T_ACROSS_S;
+        a.box[1] = a.mbc + a.my >= T_ACROSS_S ? (a.mbc + a.my - T_ACROSS_S) / T_ACROSS_S + 1 : 0;
+        a.box[2] = 1;
+        a.box[3] = a.mx >= WAVE - SHALO ? (a.mx - (WAVE - SHALO)) / SSTRIP + 1 : 0;
+    } else a.sub = 0;
     const int n_across = IXY == 1 ? a.J : a.I + (LINE - a.mbc);
     const int m_along = IXY == 1 ? a.mx : a.my;
     const int ntiles_across = (n_across + T_ACROSS_S - 1) / T_ACROSS_S;

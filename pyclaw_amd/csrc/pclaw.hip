@@ -45,7 +45,6 @@ struct pcl_solver {
     int sel = 0;          // register the put/get/bc/strip/halo calls act on
     double *scr3[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                         nullptr, nullptr, nullptr};   // unsplit 3-D slice pieces
-    double *scr[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // unsplit slice pieces ([9], [10]: qcor of the x / y slices)
     double *stage = nullptr;  // AoS staging for host transfers (qbc-sized)
     size_t stage_bytes = 0;
     unsigned long long *cfl_dev = nullptr;
@@ -438,75 +437,39 @@ __global__ void copy_frame_kernel(const double *src, double *dst, int nm, int I,
 
 // unsplit step (step2.f / step2qcor.f): x phase q -> t1, y phase updates t1 in place; transverse contributions
 // travel through LDS inside the kernels (classic.hpp), no scratch planes
-int do_unsplit_lds(pcl_solver *s, double dt) {
-    hipLaunchKernelGGL(copy_frame_kernel, dim3(256), dim3(256), 0, s->stream, s->q, s->t1, s->cfg.meqn, s->I, s->J,
+static int unsplit_frame(pcl_solver *s, hipStream_t stream) {
+    hipLaunchKernelGGL(copy_frame_kernel, dim3(256), dim3(256), 0, stream, s->q, s->t1, s->cfg.meqn, s->I, s->J,
                        s->cfg.mbc, s->pitch, s->plane);
     HIP_TRY(hipGetLastError());
-    std::string err;
-    for (int ids = 1; ids <= 2; ids++) {
-        SweepLaunch l;
-        l.a = make_args(s, s->q, s->t1, ids, dt);
-        l.a.trans = s->cfg.method[2];
-        l.a.dtd_t = dt / s->cfg.d[2 - ids];
-        l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = s->stream;
-        pcl_solver::Timed t{};
-        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = true; hipEventRecord(t.a, s->stream); }
-        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit(l, s->t1, err)
-                                              : pcl::exact::launch_unsplit(l, s->t1, err);
-        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
-        if (rc) return fail(rc, err);
-    }
     return PCL_OK;
 }
 
-// the scratch-plane form (x slices and y slices of qold into 9-11 planes, then one combine pass): kept as the
-// A/B partner of the LDS kernels, PCL_TUNE_CAPA_SCRATCH=1 selects it for grids with a capacity function
-int do_unsplit(pcl_solver *s, double dt) {
-    static const bool scratch = [] { const char *e = getenv("PCL_TUNE_CAPA_SCRATCH"); return e && atoi(e) != 0; }();
-    if (s->cfg.method[5] == 0 || !scratch) return do_unsplit_lds(s, dt);
-    const size_t qbytes = ((size_t)s->total + 16) * sizeof(double);
-    const bool qcor = s->cfg.rp == PCL_RP_SHALLOW_SPHERE_2D;   // the app's step2qcor.f
-    for (int k = 0; k < (qcor ? 11 : 9); k++) {
-        if (s->scr[k]) continue;
-        double *raw = nullptr;
-        HIP_TRY(hipMalloc((void **)&raw, qbytes));
-        HIP_TRY(hipMemsetAsync(raw, 0, qbytes, s->stream));
-        s->scr[k] = raw + s->lead;
-    }
+// one phase (ids = 1: x, 2: y); sub = 0 all tiles, 1 the tiles that read no ghost cell, 2 the others (x phase only)
+static int unsplit_phase(pcl_solver *s, int ids, double dt, int sub, hipStream_t stream) {
     std::string err;
-    for (int ids = 1; ids <= 2; ids++) {
-        SweepLaunch l;
-        l.a = make_args(s, s->q, nullptr, ids, dt);
-        l.a.trans = s->cfg.method[2];
-        l.a.dtd_t = dt / s->cfg.d[2 - ids];
-        if (ids == 1) {
-            for (int k = 0; k < 5; k++) l.a.scr[k] = s->scr[k];
-            l.a.scr[5] = s->scr[9];
-        } else {  // the y slices never write slot 2 (step2.f:214-216 keeps one parenthesised term)
-            l.a.scr[0] = s->scr[5]; l.a.scr[1] = s->scr[6]; l.a.scr[2] = nullptr;
-            l.a.scr[3] = s->scr[7]; l.a.scr[4] = s->scr[8];
-            l.a.scr[5] = s->scr[10];
-        }
-        l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = s->stream;
-        pcl_solver::Timed t{};
-        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = true; hipEventRecord(t.a, s->stream); }
-        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_slices(l, err) : pcl::exact::launch_slices(l, err);
-        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
-        if (rc) return fail(rc, err);
-    }
-    CombineArgs c;
-    c.qold = s->q; c.qnew = s->t1; c.aux = s->aux;
-    for (int k = 0; k < 5; k++) c.x[k] = s->scr[k];
-    c.y[0] = s->scr[5]; c.y[1] = s->scr[6]; c.y[2] = s->scr[7]; c.y[3] = s->scr[8];
-    c.x[5] = s->scr[9]; c.y[4] = s->scr[10];
-    c.qcor = qcor ? 1 : 0;
-    c.pitch = s->pitch; c.plane = s->plane; c.I = s->I; c.J = s->J; c.mbc = s->cfg.mbc;
-    c.mx = s->cfg.n[0]; c.my = s->cfg.n[1]; c.mcapa = s->cfg.method[5]; c.meqn = s->cfg.meqn;
-    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_combine(c, s->stream, err)
-                                          : pcl::exact::launch_combine(c, s->stream, err);
+    SweepLaunch l;
+    l.a = make_args(s, s->q, s->t1, ids, dt);
+    l.a.trans = s->cfg.method[2];
+    l.a.dtd_t = dt / s->cfg.d[2 - ids];
+    l.a.sub = sub;
+    l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = stream;
+    pcl_solver::Timed t{};
+    if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
+    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit(l, s->t1, err)
+                                          : pcl::exact::launch_unsplit(l, s->t1, err);
+    if (s->timing) { hipEventRecord(t.b, stream); s->timed.push_back(t); }
     if (rc) return fail(rc, err);
     return PCL_OK;
 }
+
+int do_unsplit_lds(pcl_solver *s, double dt) {
+    if (int rc = unsplit_frame(s, s->stream)) return rc;
+    for (int ids = 1; ids <= 2; ids++)
+        if (int rc = unsplit_phase(s, ids, dt, 0, s->stream)) return rc;
+    return PCL_OK;
+}
+
+int do_unsplit(pcl_solver *s, double dt) { return do_unsplit_lds(s, dt); }
 
 // a failed step must not leave a partial maximum behind (see read_cfl's invariant)
 int bail(pcl_solver *s, int rc) {
@@ -722,8 +685,6 @@ void pcl_destroy(pcl_solver *s) {
     for (auto &e : s->evpool) hipEventDestroy(e);
     for (double *p : {s->q, s->t1, s->t2, s->t3, s->bak, s->aux, s->stage})
         if (p) hipFree(p - s->lead);
-    for (double *p : s->scr)
-        if (p) hipFree(p - s->lead);
     for (double *p : s->scr3)
         if (p) hipFree(p - s->lead);
     for (int k = 1; k < 5; k++)
@@ -873,7 +834,9 @@ int pcl_get_cells(pcl_solver *s, int ncell, const int *ij, double *q, double *au
     return PCL_OK;
 }
 
-static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate, bool aux = false) {
+static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *cstate, bool aux = false,
+                     hipStream_t on = nullptr) {
+    const hipStream_t stream = on ? on : s->stream;
     pcl::RpParams cs;  // the constant state travels as a kernel argument: no copy, no sync
     for (int k = 0; k < 8; k++) cs.v[k] = (cstate && k < s->cfg.meqn) ? cstate[k] : 0.0;
     const int nm = aux ? s->cfg.maux : s->cfg.meqn;
@@ -882,14 +845,14 @@ static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *
         Dims3 D{{s->I, s->J, s->K}, {1, s->pitch, s->pitch * s->J}};
         const int d1 = idim == 0 ? 1 : 0, d2 = idim == 2 ? 1 : 2;
         const long n3 = (long)D.n[d1] * D.n[d2] * s->cfg.mbc * nm;
-        hipLaunchKernelGGL(bc3_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL(bc3_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, stream,
                            aux ? s->aux : cur(s), nm, D, s->plane, s->cfg.mbc, idim, side, type, aux ? 1 : 0);
         HIP_TRY(hipGetLastError());
         return PCL_OK;
     }
     const int nt = idim == 0 ? s->J : s->I;
     const long n = (long)nt * s->cfg.mbc * nm;
-    hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream,
+    hipLaunchKernelGGL(bc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        aux ? s->aux : cur(s), nm, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, idim, side, type,
                        cs, aux ? 1 : 0);
     HIP_TRY(hipGetLastError());
@@ -1001,6 +964,44 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
         if (!s->halo.has(pcl::N)) box[1] = ntiles[0];
         if (!s->halo.has(pcl::W)) box[2] = 0;
         if (!s->halo.has(pcl::E)) box[3] = ntiles[1];
+    }
+    // Decomposed unsplit 2-D step: the ghost frame (exchange, then the physical BCs) is built on the halo stream while
+    // the x phase runs the tiles that read no ghost cell; the rim tiles follow on the halo stream, the y phase (it reads
+    // every cell of qold and of the x-phase result) after the join.  PCL_HALO_OVERLAP=2: the same launches on one
+    // stream with the interior tiles strictly BEFORE the frame (race check, as for the dim-split step).
+    const bool overlapped_u = s->halo.active && s->cfg.ndim == 2 && s->cfg.method[2] >= 0 && s->overlap && s->sel == 0;
+    if (overlapped_u) {
+        std::string err;
+        const bool seq = s->overlap == 2;
+        const hipStream_t hs = seq ? s->stream : s->hstream;
+        int rc = PCL_OK;
+        if (seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);
+        else {
+            HIP_TRY(hipEventRecord(s->ev_h0, s->stream));            // q of the previous step is complete
+            HIP_TRY(hipStreamWaitEvent(hs, s->ev_h0, 0));
+        }
+        if (!rc && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, hs)) rc = fail(PCL_ECOMM, err);
+        for (int idim = 0; idim < 2 && !rc; idim++)
+            for (int side = 0; side < 2 && !rc; side++) {
+                const int t = bc[2 * idim + side];
+                if (t < 0) continue;
+                rc = t == PCL_BC_CUSTOM
+                         ? bc_launch(s, idim, side, 100, cstate + (2 * idim + side) * PCL_MAX_RP_PARAMS, false, hs)
+                         : bc_launch(s, idim, side, t, nullptr, false, hs);
+            }
+        if (!rc) rc = unsplit_frame(s, hs);
+        if (!rc && !seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);   // interior tiles, concurrent with the frame
+        if (!rc) rc = unsplit_phase(s, 1, dt, 2, hs);                  // rim tiles behind the frame
+        if (!seq) {                                                    // join, also on the error paths
+            hipError_t he = hipEventRecord(s->ev_h1, hs);
+            if (he == hipSuccess) he = hipStreamWaitEvent(s->stream, s->ev_h1, 0);
+            if (!rc && he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream join: ") + hipGetErrorString(he));
+        }
+        if (!rc) rc = unsplit_phase(s, 2, dt, 0, s->stream);
+        if (rc) return bail(s, rc);
+        std::swap(s->q, s->t1);
+        s->undo_slot = &s->t1;
+        return read_cfl(s, cfl);
     }
     if (s->halo.active && !overlapped) {
         std::string err;
@@ -1129,42 +1130,111 @@ int pcl_select(pcl_solver *s, int reg) {
     return PCL_OK;
 }
 
-static int sharp_passes(pcl_solver *s, double dt, int rk_op, const double *ra, const double *rb, double *rd,
-                        double ca, double cb, double cc) {
+// one directional pass of a stage; sub: 0 all tiles, 1 tiles that read no ghost cell, 2 the others (x pass only)
+static int sharp_pass(pcl_solver *s, int ids, double dt, int rk_op, const double *ra, const double *rb, double *rd,
+                      double ca, double cb, double cc, int sub, hipStream_t stream) {
     std::string err;
+    SweepLaunch l;
+    l.a = make_args(s, cur(s), s->sreg[PCL_REG_DQ], ids, dt);
+    l.a.sub = sub;
+    if (rk_op && ids == s->cfg.ndim) {
+        l.a.rk_op = rk_op; l.a.rk_a = ra; l.a.rk_b = rb; l.a.rk_d = rd;
+        l.a.rk_ca = ca; l.a.rk_cb = cb; l.a.rk_cc = cc;
+    }
+    l.ndim = s->cfg.ndim; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave;
+    l.lim_type = s->cfg.lim_type; l.stream = stream;
+    pcl_solver::Timed t{};
+    if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
+    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sharp(l, err) : pcl::exact::launch_sharp(l, err);
+    if (s->timing) { hipEventRecord(t.b, stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
+    if (rc) return fail(rc, err);
+    return PCL_OK;
+}
+
+// ghost frame of the selected register: halo exchange (decomposed runs), then the physical BCs in the reference's
+// order (per dimension, lower then upper); bc[k] < 0: nothing to do on that side
+static int sharp_frame(pcl_solver *s, const int *bc, const double *cstate, hipStream_t stream) {
+    std::string err;
+    if (s->halo.active && s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err, stream))
+        return fail(PCL_ECOMM, err);
+    for (int idim = 0; idim < s->cfg.ndim; idim++)
+        for (int side = 0; side < 2; side++) {
+            const int t = bc[2 * idim + side];
+            if (t < 0) continue;
+            const int rc = t == PCL_BC_CUSTOM
+                               ? bc_launch(s, idim, side, 100, cstate + (2 * idim + side) * PCL_MAX_RP_PARAMS, false, stream)
+                               : bc_launch(s, idim, side, t, nullptr, false, stream);
+            if (rc) return rc;
+        }
+    return PCL_OK;
+}
+
+// The passes of one stage.  bc != nullptr: the stage's ghost frame is built here too; in a decomposed 2-D run it is
+// built on the halo stream while the x pass runs the tiles that read no ghost cell (the rim tiles follow on the halo
+// stream, the y pass after the join) -- the SharpClaw counterpart of pcl_bc_step's choreography, ten times per
+// SSP104 step.  PCL_HALO_OVERLAP=2: same launches on one stream, interior tiles strictly BEFORE the frame.
+static int sharp_passes(pcl_solver *s, double dt, int rk_op, const double *ra, const double *rb, double *rd,
+                        double ca, double cb, double cc, const int *bc = nullptr, const double *cstate = nullptr) {
     // the fused store phase dereferences all three operands whenever rk_op != 0 (sharpclaw.hpp): a null one is a
     // memory fault at address 0 on the device, so it is refused here
     if (rk_op && (!ra || !rb || !rd)) return fail(PCL_EINVAL, "fused RK stage: null register operand");
     if (!cur(s) || !s->sreg[PCL_REG_DQ]) return fail(PCL_ESTATE, "SharpClaw registers not allocated");
-    for (int ids = 1; ids <= s->cfg.ndim; ids++) {
-        SweepLaunch l;
-        l.a = make_args(s, cur(s), s->sreg[PCL_REG_DQ], ids, dt);
-        if (rk_op && ids == s->cfg.ndim) {
-            l.a.rk_op = rk_op; l.a.rk_a = ra; l.a.rk_b = rb; l.a.rk_d = rd;
-            l.a.rk_ca = ca; l.a.rk_cb = cb; l.a.rk_cc = cc;
+    int rc = PCL_OK;
+    int first = 1;
+    if (bc && s->halo.active && s->overlap && s->cfg.ndim == 2) {
+        const bool seq = s->overlap == 2;
+        const hipStream_t hs = seq ? s->stream : s->hstream;
+        if (seq) rc = sharp_pass(s, 1, dt, rk_op, ra, rb, rd, ca, cb, cc, 1, s->stream);
+        else {
+            HIP_TRY(hipEventRecord(s->ev_h0, s->stream));            // the stage register is complete
+            HIP_TRY(hipStreamWaitEvent(hs, s->ev_h0, 0));
         }
-        l.ndim = s->cfg.ndim; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave;
-        l.lim_type = s->cfg.lim_type; l.stream = s->stream;
-        pcl_solver::Timed t{};
-        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = true; hipEventRecord(t.a, s->stream); }
-        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sharp(l, err) : pcl::exact::launch_sharp(l, err);
-        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
-        if (rc) return bail(s, fail(rc, err));
+        if (!rc) rc = sharp_frame(s, bc, cstate, hs);
+        if (!rc && !seq) rc = sharp_pass(s, 1, dt, rk_op, ra, rb, rd, ca, cb, cc, 1, s->stream);
+        if (!rc) rc = sharp_pass(s, 1, dt, rk_op, ra, rb, rd, ca, cb, cc, 2, hs);
+        if (!seq) {                                                    // join, also on the error paths
+            hipError_t he = hipEventRecord(s->ev_h1, hs);
+            if (he == hipSuccess) he = hipStreamWaitEvent(s->stream, s->ev_h1, 0);
+            if (!rc && he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream join: ") + hipGetErrorString(he));
+        }
+        first = 2;
+    } else if (bc) {
+        rc = sharp_frame(s, bc, cstate, s->stream);
+    }
+    for (int ids = first; ids <= s->cfg.ndim && !rc; ids++)
+        rc = sharp_pass(s, ids, dt, rk_op, ra, rb, rd, ca, cb, cc, 0, s->stream);
+    return rc ? bail(s, rc) : PCL_OK;
+}
+
+static int check_bc_spec(pcl_solver *s, const int *bc, const double *cstate) {
+    for (int k = 0; k < 2 * s->cfg.ndim; k++) {
+        const int t = bc[k];
+        if (t >= 0 && t != PCL_BC_CUSTOM && t != PCL_BC_OUTFLOW && t != PCL_BC_PERIODIC && t != PCL_BC_REFLECTING)
+            return fail(PCL_EINVAL, "bad boundary condition type");
+        if (t == PCL_BC_CUSTOM && !cstate) return fail(PCL_EINVAL, "constant state missing");
     }
     return PCL_OK;
 }
 
-int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl) {
+static int sharp_dq_impl(pcl_solver *s, const int *bc, const double *cstate, double dt, double *cfl) {
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_ESTATE, "SharpClaw call on a classic solver");
     if (s->sel == PCL_REG_DQ) return fail(PCL_EINVAL, "dq of the dq register");
+    if (bc) if (int rc = check_bc_spec(s, bc, cstate)) return rc;
     HIP_TRY(hipSetDevice(s->cfg.device));
-    if (int rc = sharp_passes(s, dt, 0, nullptr, nullptr, nullptr, 0, 0, 0)) return rc;
+    if (int rc = sharp_passes(s, dt, 0, nullptr, nullptr, nullptr, 0, 0, 0, bc, cstate)) return rc;
     return read_cfl(s, cfl);
 }
 
-int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, double ca, double cb, double cc,
-                    double cfl_max, double *cfl) {
+int pcl_sharp_dq(pcl_solver *s, double dt, double *cfl) { return sharp_dq_impl(s, nullptr, nullptr, dt, cfl); }
+
+int pcl_sharp_bc_dq(pcl_solver *s, const int *bc, const double *cstate, double dt, double *cfl) {
+    if (!bc) return fail(PCL_EINVAL, "null argument");
+    return sharp_dq_impl(s, bc, cstate, dt, cfl);
+}
+
+static int sharp_stage_impl(pcl_solver *s, const int *bc, const double *cstate, double dt, int op, int D, int A, int B,
+                            double ca, double cb, double cc, double cfl_max, double *cfl) {
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_ESTATE, "SharpClaw call on a classic solver");
     if (op != 1 && op != 2 && op != 5) return fail(PCL_EINVAL, "pcl_sharp_stage fuses RK ops 1, 2 and 5");
@@ -1180,13 +1250,25 @@ int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, doubl
                                     " D=" + std::to_string(D) + ")");
     // op 1 does not use B; the kernel still loads it (its store phase is branch-free, sharpclaw.hpp): point it at A
     // so that the load hits the line A's load just brought in instead of streaming another array
-    if (int rc = sharp_passes(s, dt, op, reg(A), op == 1 ? reg(A) : reg(B), spare, ca, cb, cc)) return rc;
+    if (bc) if (int rc = check_bc_spec(s, bc, cstate)) return rc;
+    if (int rc = sharp_passes(s, dt, op, reg(A), op == 1 ? reg(A) : reg(B), spare, ca, cb, cc, bc, cstate)) return rc;
     if (int rc = read_cfl(s, cfl)) return rc;
     if (*cfl <= cfl_max) {
         std::swap(reg(D), s->sreg[PCL_REG_TMP]);
         s->undo_slot = nullptr;
     }
     return PCL_OK;
+}
+
+int pcl_sharp_stage(pcl_solver *s, double dt, int op, int D, int A, int B, double ca, double cb, double cc,
+                    double cfl_max, double *cfl) {
+    return sharp_stage_impl(s, nullptr, nullptr, dt, op, D, A, B, ca, cb, cc, cfl_max, cfl);
+}
+
+int pcl_sharp_bc_stage(pcl_solver *s, const int *bc, const double *cstate, double dt, int op, int D, int A, int B,
+                       double ca, double cb, double cc, double cfl_max, double *cfl) {
+    if (!bc) return fail(PCL_EINVAL, "null argument");
+    return sharp_stage_impl(s, bc, cstate, dt, op, D, A, B, ca, cb, cc, cfl_max, cfl);
 }
 
 int pcl_rk_op(pcl_solver *s, int op, int D, int A, int B, int Cc, double ca, double cb, double cc) {

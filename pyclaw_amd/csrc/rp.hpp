@@ -1009,7 +1009,6 @@ struct ShallowSphere {
     __device__ static __forceinline__ void transverse_vc(const Cell &c1, const double *auxo, const double *auxb,
                                                          const double *auxa, const RpParams &par,
                                                          const double (&asdq)[4], double (&bm)[4], double (&bp)[4]) {
-        const double g = par.v[0];
         const double dx = IXY == 1 ? par.v[1] : par.v[2];
         const Recip by_dx(dx);
         const double h = c1.q[0];

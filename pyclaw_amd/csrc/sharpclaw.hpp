@@ -161,6 +161,10 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
     const int m_across = IXY == 1 ? a.my : a.mx;
     const int tb = IXY == 1 ? blockIdx.x / ntiles_along : blockIdx.x % ntiles_across;
     const int ta = IXY == 1 ? blockIdx.x % ntiles_along : blockIdx.x / ntiles_across;
+    if (IXY == 1 && a.sub != 0) {   // decomposed run: tiles that read no ghost cell (box) / the others (pclaw.hip)
+        const bool inside = tb >= a.box[0] && tb < a.box[1] && ta >= a.box[2] && ta < a.box[3];
+        if ((a.sub == 1) != inside) return;             // workgroup-uniform, before any barrier
+    }
     const int b0 = IXY == 1 ? tb * T_ACROSS_S : tb * T_ACROSS_S - (LINE - a.mbc);
     const int a0 = a.mbc - SHALO + ta * SSTRIP;
 

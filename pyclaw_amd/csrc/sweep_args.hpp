@@ -55,19 +55,6 @@ struct SweepArgs {
     // unsplit algorithm (step2.f) only:
     int trans;        // method(3): 0 no transverse terms, 1 increment waves, 2 + correction waves
     double dtd_t;     // dt/d of the transverse direction
-    double *scr[6];   // per-slice pieces, combined in the reference's order by combine_kernel ([5]: dt/d * qcor)
-};
-
-// Pointers for the unsplit combine pass (step2.f:130-137,214-218 accumulation order)
-struct CombineArgs {
-    const double *qold;
-    double *qnew;
-    const double *aux;
-    const double *x[6];  // x slices: qadd, dtdx*df (or S with capa), dtdy*dg, dtdy*gadd1, dtdy*gadd2, dtdx*qcor
-    const double *y[5];  // y slices: mid (or qadd with capa), S (capa only), dtdx*gadd1, dtdx*gadd2, dtdy*qcor
-    long pitch, plane;
-    int I, J, mbc, mx, my, mcapa, meqn;
-    int qcor;            // step2qcor.f instead of step2.f (shallow water on the sphere)
 };
 
 // unsplit 3-D (classic3.hpp): one direction's slices into 14 scratch plane sets, then the ordered combine
@@ -109,9 +96,7 @@ int launch_sweep(const SweepLaunch &l, std::string &err);
 // ntiles[0], ntiles[1] = row tiles / tiles along a row of the x pass
 bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]);
 int launch_sweep3(const SweepLaunch &l, std::string &err);   // 3-D dim-split sweep, l.ids = direction 1..3
-int launch_slices(const SweepLaunch &l, std::string &err);   // unsplit: per-slice pieces -> scratch
 int launch_unsplit3(const Unsplit3Launch &l, std::string &err);   // unsplit 3-D: slices + combine of one direction
-int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase
 int launch_sharp(const SweepLaunch &l, std::string &err);     // SharpClaw dq of one direction
 int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
@@ -119,9 +104,7 @@ int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 namespace fast {
 int launch_sweep(const SweepLaunch &l, std::string &err);
 int launch_sweep3(const SweepLaunch &l, std::string &err);
-int launch_slices(const SweepLaunch &l, std::string &err);
 int launch_unsplit3(const Unsplit3Launch &l, std::string &err);
-int launch_combine(const CombineArgs &c, hipStream_t stream, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase
 int launch_sharp(const SweepLaunch &l, std::string &err);
 int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);

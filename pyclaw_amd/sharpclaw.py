@@ -132,10 +132,16 @@ class SharpClawSolver(Solver):
         stg.t = t
         _lib.check(L.pcl_select(self._h, reg))
         try:
-            self.apply_q_bcs(stg)
             cfl = ctypes.c_double(0.0)
-            _lib.check(L.pcl_sharp_stage(self._h, self.dt, op, D, A, B, ca, cb, cc, float(self.cfl_max),
-                                         ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+            spec = self._device_bc_spec(self._state)
+            if spec is not None:
+                # every ghost fill runs on the device: exchange + BCs + both passes + the combination in one call
+                _lib.check(L.pcl_sharp_bc_stage(self._h, spec[2], spec[3], self.dt, op, D, A, B, ca, cb, cc,
+                                                float(self.cfl_max), ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+            else:
+                self.apply_q_bcs(stg)
+                _lib.check(L.pcl_sharp_stage(self._h, self.dt, op, D, A, B, ca, cb, cc, float(self.cfl_max),
+                                             ctypes.cast(ctypes.byref(cfl), _lib.dp)))
         finally:
             _lib.check(L.pcl_select(self._h, Q))
         self.cfl.update_global_max(cfl.value)
@@ -177,9 +183,14 @@ class SharpClawSolver(Solver):
         st.t = t
         _lib.check(L.pcl_select(self._h, reg))
         try:
-            self.apply_q_bcs(st)
             cfl = ctypes.c_double(0.0)
-            _lib.check(L.pcl_sharp_dq(self._h, self.dt, ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+            spec = self._device_bc_spec(self._state)
+            if spec is not None:
+                _lib.check(L.pcl_sharp_bc_dq(self._h, spec[2], spec[3], self.dt,
+                                             ctypes.cast(ctypes.byref(cfl), _lib.dp)))
+            else:
+                self.apply_q_bcs(st)
+                _lib.check(L.pcl_sharp_dq(self._h, self.dt, ctypes.cast(ctypes.byref(cfl), _lib.dp)))
         finally:
             _lib.check(L.pcl_select(self._h, Q))
         self.cfl.update_global_max(cfl.value)

@@ -271,3 +271,193 @@ def test_overlapped_step_partial_neighbours(axis, overlap, monkeypatch):
             lib.pcl_destroy(h)
     assert res[0][1] == res[1][1] and res[0][1][0] > 0
     assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
+
+
+def make_unsplit_solver(L, mx, my, capa):
+    cfg = L.Config()
+    cfg.ndim = 2
+    cfg.n[0], cfg.n[1] = mx, my
+    cfg.mbc = 2
+    cfg.meqn, cfg.mwaves, cfg.rp = 5, 5, 11
+    cfg.maux = 1 if capa else 0
+    cfg.method[1] = 2
+    cfg.method[2] = 2            # unsplit, transverse increment + correction waves
+    cfg.method[5] = 1 if capa else 0
+    cfg.method[6] = cfg.maux
+    for k in range(cfg.mwaves):
+        cfg.mthlim[k] = 4
+    cfg.rp_params[0], cfg.rp_params[1] = 1.4, 0.4
+    cfg.d[0], cfg.d[1] = 1.0 / mx, 1.0 / my
+    h = C.c_void_p()
+    L.check(L.lib().pcl_create(C.byref(cfg), C.byref(h)))
+    return h
+
+
+@pytest.mark.parametrize("mx,my,overlap,capa", [(300, 47, 1, False), (300, 47, 2, False), (300, 47, 0, False),
+                                                    (190, 31, 2, True), (190, 31, 1, True), (61, 13, 2, False),
+                                                    (125, 16, 2, False)])
+def test_overlapped_unsplit_step_equals_periodic(mx, my, overlap, capa, monkeypatch):
+    """The unsplit step (step2.f) of a block whose 8 neighbours are itself: ghost frame built on the halo stream while
+    the x phase runs the tiles that read no ghost cell, rim tiles behind it, y phase after the join == the same steps
+    with local periodic fills, bit for bit.  overlap=2: interior tiles strictly BEFORE the exchange over a NaN-poisoned
+    ghost frame (race check); overlap=0: sequential exchange; (61, 13) has no interior tile at all."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    monkeypatch.setenv("PCL_HALO_OVERLAP", str(overlap))
+    g = 2
+    rng = np.random.default_rng(23)
+    q0 = np.empty((5, mx, my), order="F")
+    q0[0] = 1 + 0.3 * rng.random((mx, my))
+    q0[1] = 0.3 * rng.standard_normal((mx, my))
+    q0[2] = 0.2 * rng.standard_normal((mx, my))
+    q0[3] = 2.5 + 0.5 * rng.random((mx, my))
+    q0[4] = rng.random((mx, my))
+    aux = np.asfortranarray(np.pad(1.0 + 0.3 * rng.random((1, mx, my)), ((0, 0), (g, g), (g, g)), mode="wrap"))
+    res = []
+    for with_comm in (False, True):
+        h = make_unsplit_solver(L, mx, my, capa)
+        try:
+            if capa:
+                L.check(lib.pcl_put_aux(h, L.d(aux)))
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
+                bc = np.full(4, -1, dtype=np.int32)
+            else:
+                bc = np.full(4, 2, dtype=np.int32)
+            poison = np.full((5, mx + 2 * g, my + 2 * g), np.nan, order="F")
+            L.check(lib.pcl_put_q(h, L.d(poison), 1))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            cfls = []
+            for _ in range(3):
+                cfl = C.c_double()
+                L.check(lib.pcl_bc_step(h, L.i(bc), L.d(np.zeros(32)), 2e-4 * 100 / mx, C.cast(C.byref(cfl), L.dp)))
+                cfls.append(cfl.value)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            res.append((out, cfls))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and 0 < res[0][1][0] < 1
+    assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
+    assert not np.array_equal(res[0][0], q0)
+
+
+@pytest.mark.parametrize("overlap", [1, 2])
+@pytest.mark.parametrize("axis", ["x", "y"])
+def test_overlapped_unsplit_partial_neighbours(axis, overlap, monkeypatch):
+    """Unsplit step with neighbours on one axis only (self, periodic strip) and physical BCs (reflecting lower,
+    outflow upper) on the other: the BC fills run on the halo stream behind the exchange (corner ghosts read
+    exchanged cells).  == local periodic fills on that axis, bit for bit."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    monkeypatch.setenv("PCL_HALO_OVERLAP", str(overlap))
+    mx, my, g = 250, 41, 2
+    rng = np.random.default_rng(6)
+    q0 = np.empty((5, mx, my), order="F")
+    q0[0] = 1 + 0.3 * rng.random((mx, my))
+    q0[1] = 0.3 * rng.standard_normal((mx, my))
+    q0[2] = 0.2 * rng.standard_normal((mx, my))
+    q0[3] = 2.5 + 0.5 * rng.random((mx, my))
+    q0[4] = rng.random((mx, my))
+    res = []
+    for with_comm in (False, True):
+        h = make_unsplit_solver(L, mx, my, False)
+        try:
+            if axis == "x":
+                nbr = np.array([0, 0, -1, -1, -1, -1, -1, -1], dtype=np.int32)
+                bc_comm, bc_loc = [-1, -1, 3, 1], [2, 2, 3, 1]
+            else:
+                nbr = np.array([-1, -1, 0, 0, -1, -1, -1, -1], dtype=np.int32)
+                bc_comm, bc_loc = [3, 1, -1, -1], [3, 1, 2, 2]
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(nbr)))
+            bc = np.array(bc_comm if with_comm else bc_loc, dtype=np.int32)
+            poison = np.full((5, mx + 2 * g, my + 2 * g), np.nan, order="F")
+            L.check(lib.pcl_put_q(h, L.d(poison), 1))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            cfls = []
+            for _ in range(3):
+                cfl = C.c_double()
+                L.check(lib.pcl_bc_step(h, L.i(bc), L.d(np.zeros(32)), 1e-4, C.cast(C.byref(cfl), L.dp)))
+                cfls.append(cfl.value)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            res.append((out, cfls))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and res[0][1][0] > 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
+
+
+def make_sharp_solver(L, mx, my, lim=2):
+    cfg = L.Config()
+    cfg.ndim = 2
+    cfg.n[0], cfg.n[1] = mx, my
+    cfg.d[0], cfg.d[1] = 1.0 / mx, 1.0 / my
+    cfg.mbc = 3
+    cfg.meqn, cfg.mwaves, cfg.rp = 5, 5, 11
+    cfg.method[1] = 2
+    cfg.rp_params[0], cfg.rp_params[1] = 1.4, 0.4
+    cfg.kind = 1
+    cfg.lim_type = lim
+    h = C.c_void_p()
+    L.check(L.lib().pcl_create(C.byref(cfg), C.byref(h)))
+    return h
+
+
+@pytest.mark.parametrize("mx,my,overlap", [(300, 70, 1), (300, 70, 2), (300, 70, 0), (140, 33, 2), (60, 20, 2)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_overlapped_sharpclaw_stage_equals_periodic(mx, my, overlap, fused, monkeypatch):
+    """SharpClaw stages (frame + flux2 + forward-Euler combination q += dq, three in a row) on a block whose 8
+    neighbours are itself: the stage's ghost frame is built on the halo stream while the x pass runs the tiles that
+    read no ghost cell == the same stages with local periodic fills, bit for bit.  overlap=2: interior tiles strictly
+    BEFORE the exchange over a NaN-poisoned ghost frame; (60, 20) has no interior tile.  fused=False: pcl_sharp_bc_dq
+    + a separate register operation."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    monkeypatch.setenv("PCL_HALO_OVERLAP", str(overlap))
+    g = 3
+    rng = np.random.default_rng(31)
+    q0 = np.empty((5, mx, my), order="F")
+    q0[0] = 1 + 0.3 * rng.random((mx, my))
+    q0[1] = 0.3 * rng.standard_normal((mx, my))
+    q0[2] = 0.2 * rng.standard_normal((mx, my))
+    q0[3] = 2.5 + 0.5 * rng.random((mx, my))
+    q0[4] = rng.random((mx, my))
+    res = []
+    for with_comm in (False, True):
+        h = make_sharp_solver(L, mx, my)
+        try:
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
+                bc = np.full(4, -1, dtype=np.int32)
+            else:
+                bc = np.full(4, 2, dtype=np.int32)
+            poison = np.full((5, mx + 2 * g, my + 2 * g), np.nan, order="F")
+            L.check(lib.pcl_put_q(h, L.d(poison), 1))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            cfls = []
+            dt = 2e-4 * 100 / mx
+            for _ in range(3):
+                cfl = C.c_double()
+                if fused:
+                    L.check(lib.pcl_sharp_bc_stage(h, L.i(bc), L.d(np.zeros(32)), dt, 1, 0, 0, 0, 1.0, 0.0, 0.0, 1e9,
+                                                   C.cast(C.byref(cfl), L.dp)))
+                else:
+                    L.check(lib.pcl_sharp_bc_dq(h, L.i(bc), L.d(np.zeros(32)), dt, C.cast(C.byref(cfl), L.dp)))
+                    L.check(lib.pcl_rk_op(h, 1, 0, 0, 3, 0, 1.0, 0.0, 0.0))       # q = q + dq/1
+                cfls.append(cfl.value)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            res.append((out, cfls))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and 0 < res[0][1][0] < 1
+    assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
+    assert not np.array_equal(res[0][0], q0)
