@@ -133,14 +133,15 @@ def build_sharp(nx, ny, math):
     return claw
 
 
-def build3d(n, math):
+def build3d(n, math, unsplit=False):
     """3-D synthetic workload: the reference's 3-D acoustics app (test/acoustics/3d/acoustics.py, 'hom' set-up:
     dim-split, periodic) on an n[0] x n[1] x n[2] grid with a two-material aux field."""
     import pyclaw_amd as pyclaw
     from apps import problems
     if isinstance(n, int):
         n = (n, n, n)
-    claw = problems.acoustics3D(pyclaw, mx=n[0], my=n[1], mz=n[2], run=False, math=math)
+    claw = problems.acoustics3D(pyclaw, test='het' if unsplit else 'hom', mx=n[0], my=n[1], mz=n[2], run=False,
+                                math=math)        # 'het' = the reference's unsplit step3 set-up (order_trans 22)
     st = claw.solution.state
     X, Y, Z = st.grid.c_center
     st.aux[0] = 1.0 + (X >= 0.)                     # impedance 1 | 2
@@ -343,7 +344,10 @@ def main():
         args.ny = args.nx
         pd = parallel.proc_grid([args.nx, args.nx], size) if size > 1 else [1, 1]
         dims, nxg, nyg = [1] + pd, args.nx, args.nx * pd[0]
-        claw = build3d((args.nx, args.nx * pd[0], args.nx * pd[1]), args.math)
+        if args.unsplit and size != 1:
+            sys.stderr.write("bench.py --ndim 3 --unsplit runs on one GPU here\n")
+            sys.exit(2)
+        claw = build3d((args.nx, args.nx * pd[0], args.nx * pd[1]), args.math, args.unsplit)
     elif args.app == "sphere":
         if size != 1:
             sys.stderr.write("bench.py --app sphere runs on one GPU here (the pole boundary mirrors whole rows)\n")
@@ -354,10 +358,10 @@ def main():
         dims, nxg, nyg = [1, 1], args.nx, args.ny
         claw = build_sphere(nxg, nyg, args.math, args.solver)
     elif args.solver == "sharpclaw":
-        if size != 1:
-            sys.stderr.write("bench.py --solver sharpclaw runs on one GPU here\n")
-            sys.exit(2)
-        dims, nxg, nyg = [1, 1], args.nx, args.ny
+        # weak scaling like the classic line: nx x ny cells per GPU; every stage's halo exchange overlaps the
+        # interior tiles of its x pass (pcl_sharp_bc_stage)
+        dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
+        nxg, nyg = args.nx * dims[0], args.ny * dims[1]
         claw = build_sharp(nxg, nyg, args.math)
     elif args.glob is not None:
         # strong scaling: the global grid is fixed and cut into px x py blocks (PETSc DMDA rule, parallel.py)
@@ -394,6 +398,11 @@ def main():
             # per directional sweep: read q (4) + aux (2), write q (4) doubles per cell
             names = [ns + "sweep3_kernel<VcAcoustics3D, 1> (x sweep)", ns + "sweep3_kernel<VcAcoustics3D, 2|3> (y, z sweeps)"]
             bytes_launch = (4 + 2 + 4) * 8 * float(args.nx) ** 3
+            if args.unsplit:
+                # per direction: slices3 (q + aux in, 14 scratch plane sets out) + combine3 (q + scratch in, q out);
+                # the timed launches are the two kernels of one direction together
+                names = [ns + "slices3 + combine3 <VcAcoustics3D, 1> (x direction)",
+                         ns + "slices3 + combine3 <VcAcoustics3D, 2|3> (y, z directions)"]
         if args.solver == "sharpclaw":
             # x pass: read the stage (5), write dq (5); y pass: read the stage, dq and the RK operand, write the result
             names = [ns + "sharp_kernel<Euler5, 1> (x pass of one RK stage)",
@@ -426,8 +435,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": ("test/acoustics/3d 3-D variable-coefficient acoustics, %d^3 cells, classic dim-split "
-                                    "(step3ds), MC limiter, order 2" % args.nx) if args.ndim == 3 else
+            "config": {"workload": ("test/acoustics/3d 3-D variable-coefficient acoustics, %d^3 cells, classic %s, MC "
+                                    "limiter, order 2" % (args.nx, "UNSPLIT (step3, order_trans 22)" if args.unsplit
+                                                          else "dim-split (step3ds)")) if args.ndim == 3 else
                                    "apps/euler 2D shock-bubble, %s, classic %s, "
                                    "mthlim=[4,4,4,4,2], order 2, source off"
                                    % (grid_note, "UNSPLIT order_trans=2" if args.unsplit else "dim-split"),

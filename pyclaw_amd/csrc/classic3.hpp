@@ -51,17 +51,30 @@ template <class RP, int DIR>
 __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t, int ntiles_al) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES, NAUX = RP::NAUX;
     using Cell = typename RP::Cell;
-    // grid: x = strips along the sweep, y = y-like index, z = z-like index; 4 wavefronts = 4 consecutive y-like rows
+    // One wavefront = one 64-cell strip along the sweep; a workgroup = 4 strips.  x direction: 4 consecutive y-like
+    // rows.  y and z directions: the lanes' accesses are `pitch` apart, so the 4 wavefronts of a workgroup -- and
+    // consecutive workgroups, kept on one XCD by xcd_logical_block -- take CONSECUTIVE i: together they use whole
+    // 128-byte lines while those are still in that XCD's L2 (with i spread over blockIdx.y every line was fetched
+    // from / written to HBM up to 16 times: 54 ms instead of 6 ms per direction at 256^3).
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    const int ta = blockIdx.x % ntiles_al;
-    const int ce = (blockIdx.x / ntiles_al) * 4 + wv + t.lo_e;
-    const int cf = blockIdx.y + t.lo_f;
-    if (ce > t.hi_e) return;                                   // wave-uniform
+    int ta, ce, cf;
+    if (DIR == 1) {
+        ta = blockIdx.x % ntiles_al;
+        ce = (blockIdx.x / ntiles_al) * 4 + wv + t.lo_e;
+        cf = blockIdx.y + t.lo_f;
+    } else {
+        const int bx = xcd_logical_block(a.xcd);
+        const int ngrp = gridDim.x / ntiles_al;                // groups of 4 consecutive i
+        const int ci = (bx % ngrp) * 4 + wv;
+        ta = bx / ngrp;
+        if (DIR == 2) { cf = ci + t.lo_f; ce = blockIdx.y + t.lo_e; }   // y sweep: z-like index = i
+        else { ce = ci + t.lo_e; cf = blockIdx.y + t.lo_f; }           // z sweep: y-like index = i
+    }
+    if (ce > t.hi_e || cf > t.hi_f) return;                    // wave-uniform
     const int a0 = a.mbc - HALO + ta * STRIP;
     const int ca = a0 + lane;
     const int cc = ca < a.n_al ? ca : a.n_al - 1;
     const long g = (long)cc * a.s_al + (long)ce * t.s_e + (long)cf * t.s_f;
-    const long gl = (long)(cc > 0 ? cc - 1 : 0) * a.s_al + (long)ce * t.s_e + (long)cf * t.s_f;
     double q[MEQN], auxv[NAUX];
 #pragma unroll
     for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + g];
@@ -69,7 +82,13 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
     for (int k = 0; k < NAUX; k++) auxv[k] = a.aux[aux_idx<RP, DIR>(k) * a.plane + g];
     double blkR[3][3][NAUX], blkL[3][3][NAUX];
     load_blk<RP, DIR>(a, t, g, ce, cf, blkR);     // cell l: A^+ dq of interface l sits here
-    load_blk<RP, DIR>(a, t, gl, ce, cf, blkL);    // cell l-1: A^- dq
+    // cell l-1 (A^- dq): the left lane's block (lane 0 has no interface of its own)
+#pragma unroll
+    for (int oe = 0; oe < 3; oe++)
+#pragma unroll
+        for (int of = 0; of < 3; of++)
+#pragma unroll
+            for (int k = 0; k < NAUX; k++) blkL[oe][of][k] = from_left(blkR[oe][of][k]);
 
     const double d = a.dtd;
     const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
@@ -310,11 +329,15 @@ struct Combine3Args {
     double dtd, dty, dtz;
     int e_outer;          // 1: the Fortran's outer loop runs over the y-like index (y sweep), 0: over the z-like one
     int first;            // 1: x direction (start from qsrc and write every cell, ghost cells copied through)
+    int dir;              // sweep direction 1..3 (thread -> cell mapping)
 };
 __global__ __launch_bounds__(256) void combine3_kernel(Combine3Args c) {
-    const int ia = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ie = blockIdx.y, jf = blockIdx.z;
-    if (ia >= c.n_al) return;
+    // threads run along i (memory-contiguous) whatever the sweep direction: every load and the store are coalesced
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x, pj = blockIdx.y, pk = blockIdx.z;
+    const int ia = c.dir == 1 ? pi : (c.dir == 2 ? pj : pk);       // index along the sweep
+    const int ie = c.dir == 1 ? pj : (c.dir == 2 ? pk : pi);       // y-like
+    const int jf = c.dir == 1 ? pk : (c.dir == 2 ? pi : pj);       // z-like
+    if (ia >= c.n_al || ie >= c.n_e || jf >= c.n_f) return;
     const long g = (long)ia * c.s_al + (long)ie * c.s_e + (long)jf * c.s_f;
     const bool interior = ia >= c.mbc && ia < c.mbc + c.m_al && ie >= c.mbc && ie < c.mbc + c.m_e && jf >= c.mbc &&
                           jf < c.mbc + c.m_f;

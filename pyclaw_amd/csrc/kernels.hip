@@ -125,8 +125,9 @@ template <class RP, int DIR> int launch_unsplit3_t(const Unsplit3Launch &l, std:
     t.lo_e = a.mbc - 1; t.hi_e = a.mbc + l.m_e; t.lo_f = a.mbc - 1; t.hi_f = a.mbc + l.m_f;
     t.m3 = l.m3; t.m4 = l.m4; t.dty = l.dty; t.dtz = l.dtz;
     const int ntiles_al = (a.m_al + STRIP - 1) / STRIP;
-    const int rows = l.m_e + 2, rowtiles = (rows + 3) / 4;
-    hipLaunchKernelGGL((slices3_kernel<RP, DIR>), dim3((unsigned)ntiles_al * rowtiles, (unsigned)(l.m_f + 2)), dim3(256), 0,
+    // workgroups of 4 strips: 4 consecutive y-like rows (x direction) / 4 consecutive i (y, z directions; classic3.hpp)
+    const int n4 = DIR == 2 ? l.m_f + 2 : l.m_e + 2, nother = DIR == 2 ? l.m_e + 2 : l.m_f + 2;
+    hipLaunchKernelGGL((slices3_kernel<RP, DIR>), dim3((unsigned)ntiles_al * ((n4 + 3) / 4), (unsigned)nother), dim3(256), 0,
                        l.stream, a, t, ntiles_al);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(err, "slices3 launch", e);
@@ -137,7 +138,11 @@ template <class RP, int DIR> int launch_unsplit3_t(const Unsplit3Launch &l, std:
     c.meqn = RP::MEQN; c.dtd = a.dtd; c.dty = l.dty; c.dtz = l.dtz;
     c.e_outer = DIR == 2 ? 1 : 0;       // step3.f: y sweeps loop k (their y-like index) outside, x and z sweeps inside
     c.first = DIR == 1 ? 1 : 0;
-    hipLaunchKernelGGL(combine3_kernel, dim3((unsigned)((a.n_al + 255) / 256), (unsigned)l.n_e, (unsigned)l.n_f), dim3(256), 0,
+    c.dir = DIR;
+    const int ni = DIR == 1 ? a.n_al : (DIR == 2 ? l.n_f : l.n_e);     // physical extents (i, j, k) of the block
+    const int nj = DIR == 1 ? l.n_e : (DIR == 2 ? a.n_al : l.n_f);
+    const int nk = DIR == 1 ? l.n_f : (DIR == 2 ? l.n_e : a.n_al);
+    hipLaunchKernelGGL(combine3_kernel, dim3((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk), dim3(256), 0,
                        l.stream, c);
     e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "combine3 launch", e);
