@@ -68,6 +68,23 @@ template <class RP> __host__ __device__ constexpr int naux_t() {
     if constexpr (RP::NAUX > 0) return RP::NAUX_T;
     else return 0;
 }
+// number of aux planes the y phase of the unsplit kernel stages (highest plane index read + 1), and which of them
+template <class RP> __host__ __device__ constexpr int aux_planes_y() {
+    int n = 0;
+    if constexpr (RP::NAUX > 0) {
+        for (int k = 0; k < RP::NAUX; k++) n = aux_idx<RP, 2>(k) + 1 > n ? aux_idx<RP, 2>(k) + 1 : n;
+        for (int k = 0; k < RP::NAUX_T; k++) n = auxt_idx<RP, 2>(k) + 1 > n ? auxt_idx<RP, 2>(k) + 1 : n;
+    }
+    return n;
+}
+template <class RP> __host__ __device__ constexpr bool aux_plane_used_y(int p) {
+    bool u = false;
+    if constexpr (RP::NAUX > 0) {
+        for (int k = 0; k < RP::NAUX; k++) u = u || aux_idx<RP, 2>(k) == p;
+        for (int k = 0; k < RP::NAUX_T; k++) u = u || auxt_idx<RP, 2>(k) == p;
+    }
+    return u;
+}
 template <class RP, class = void> struct IsFwave : std::false_type {};
 template <class RP> struct IsFwave<RP, std::void_t<decltype(RP::IS_FWAVE)>> : std::bool_constant<RP::IS_FWAVE> {};
 template <class RP, class = void> struct HasQcor : std::false_type {};
@@ -809,6 +826,14 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
     constexpr int TP = U_WAVES + 1;
     __shared__ double tile[MEQN][WAVE][TP];
     __shared__ double gm[U_WAVES][MEQN][WAVE], gp[U_WAVES][MEQN][WAVE];
+    // aux planes of the solver, columns i0-1 .. i0+U_WAVES (the transverse solves read the neighbouring columns):
+    // loaded with coalesced row segments like q; per-lane loads of a column are `pitch` apart (64 lines per
+    // instruction, 9 + 27 of them for the sphere solver)
+    // (where all of it fits the 160 KB: the sphere solver's 16 planes do with 8 slices per workgroup, its default)
+    constexpr int AC = U_WAVES + 2, AP = AC + 1;
+    constexpr long LDS_REST = (long)sizeof(double) * (MEQN * WAVE * TP + 2 * U_WAVES * MEQN * WAVE);
+    constexpr int NPL = LDS_REST + (long)sizeof(double) * aux_planes_y<RP>() * WAVE * AP <= 160 * 1024 ? aux_planes_y<RP>() : 0;
+    __shared__ double atile[NPL > 0 ? NPL : 1][NPL > 0 ? WAVE : 1][NPL > 0 ? AP : 1];
     const int bid = xcd_logical_block(a.xcd);
     const int ti = bid % ntiles_i, tj = bid / ntiles_i;
     const int i0 = a.mbc - 1 + ti * U_OUT;               // slices i = 0 .. mx+1  <->  columns mbc-1 .. mbc+mx
@@ -821,6 +846,18 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
         const long g = (long)gj * a.pitch + gi;
 #pragma unroll
         for (int m = 0; m < MEQN; m++) tile[m][r][c] = a.qin[m * a.plane + g];
+    }
+    if constexpr (NPL > 0) {
+        for (int idx = threadIdx.x; idx < WAVE * AC; idx += U_WAVES * WAVE) {
+            const int c = idx % AC, r = idx / AC;
+            int gi = i0 - 1 + c, gj = j0 + r;
+            gi = gi < 0 ? 0 : (gi < a.I ? gi : a.I - 1);
+            gj = gj < a.J ? gj : a.J - 1;
+            const long g = (long)gj * a.pitch + gi;
+#pragma unroll
+            for (int p = 0; p < NPL; p++)
+                if (aux_plane_used_y<RP>(p)) atile[p][r][c] = a.aux[p * a.plane + g];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & (WAVE - 1);
@@ -837,7 +874,16 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
     constexpr int NAUX = RP::NAUX;
     constexpr int NT = naux_t<RP>() > 0 ? naux_t<RP>() : 1;
     double auxv[NAUX > 0 ? NAUX : 1], auxo[NT], auxb[NT], auxa[NT];
-    if constexpr (NAUX > 0) {
+    if constexpr (NAUX > 0 && NPL > 0) {     // column w of the tile = column w+1 of atile
+#pragma unroll
+        for (int m = 0; m < NAUX; m++) auxv[m] = atile[aux_idx<RP, 2>(m)][lane][w + 1];
+#pragma unroll
+        for (int m = 0; m < NT; m++) {
+            auxo[m] = atile[auxt_idx<RP, 2>(m)][lane][w + 1];
+            auxb[m] = atile[auxt_idx<RP, 2>(m)][lane][w];
+            auxa[m] = atile[auxt_idx<RP, 2>(m)][lane][w + 2];
+        }
+    } else if constexpr (NAUX > 0) {
         const int gj = cj < a.J ? cj : a.J - 1;
         const int c0 = col < a.I ? col : a.I - 1;
         const int cb = c0 > 0 ? c0 - 1 : 0, cn = c0 + 1 < a.I ? c0 + 1 : a.I - 1;

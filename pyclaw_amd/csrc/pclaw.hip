@@ -423,23 +423,57 @@ int do_unsplit3(pcl_solver *s, double dt) {
     return PCL_OK;
 }
 
-// copy the ghost frame (every cell outside the interior) of an nm-plane array
-__global__ void copy_frame_kernel(const double *src, double *dst, int nm, int I, int J, int mbc, long pitch,
-                                  long plane) {
+// Ghost frame of the unsplit step in ONE launch: every cell outside the interior gets its boundary value -- the
+// composition of the per-side fills of solver.py:354-452 (x sides first, then y sides over the x-filled columns, so a
+// corner cell is the y rule applied to an x-ghost cell) written as an index remap, like the dim-split x pass does
+// while loading its tiles -- and is copied to dst (the y phase updates t1 in place and its ghost frame must equal
+// qold's).  bc[k] < 0: no fill on that side (neighbour block or a fill done elsewhere); 100 = constant state.
+struct FrameBc { int t[4]; double c[4][8]; };
+__device__ __forceinline__ void frame_map(int k, int n, int mbc, int lo, int hi, int &src, bool &neg, bool &cst, int &side) {
+    src = k; neg = false; cst = false; side = 0;
+    if (k < mbc && lo >= 0) {
+        if (lo == PCL_BC_OUTFLOW) src = mbc;
+        else if (lo == PCL_BC_PERIODIC) src = n - 2 * mbc + k;
+        else if (lo == PCL_BC_REFLECTING) { src = 2 * mbc - 1 - k; neg = true; }
+        else cst = true;
+    } else if (k >= n - mbc && hi >= 0) {
+        side = 1;
+        if (hi == PCL_BC_OUTFLOW) src = n - mbc - 1;
+        else if (hi == PCL_BC_PERIODIC) src = k - (n - 2 * mbc);
+        else if (hi == PCL_BC_REFLECTING) { src = 2 * (n - mbc) - 1 - k; neg = true; }
+        else cst = true;
+    }
+}
+__global__ void frame_kernel(double *q, double *dst, int nm, int I, int J, int mbc, long pitch, long plane, FrameBc f) {
     const long ncell = (long)I * J;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell; t += (long)gridDim.x * blockDim.x) {
         const int i = (int)(t % I), j = (int)(t / I);
         if (i >= mbc && i < I - mbc && j >= mbc && j < J - mbc) continue;
-        const long g = (long)j * pitch + i;
-        for (int m = 0; m < nm; m++) dst[m * plane + g] = src[m * plane + g];
+        int si, sj, sdi, sdj;
+        bool ni, nj, ci, cj;
+        frame_map(i, I, mbc, f.t[0], f.t[1], si, ni, ci, sdi);
+        frame_map(j, J, mbc, f.t[2], f.t[3], sj, nj, cj, sdj);
+        const long g = (long)j * pitch + i, gs = (long)sj * pitch + si;
+        for (int m = 0; m < nm; m++) {
+            double v = q[m * plane + gs];
+            if (m == 1) v = ni ? -v : v;
+            v = ci ? f.c[sdi][m < 8 ? m : 7] : v;
+            if (m == 2) v = nj ? -v : v;
+            v = cj ? f.c[2 + sdj][m < 8 ? m : 7] : v;
+            if (gs != g) q[m * plane + g] = v;
+            if (dst) dst[m * plane + g] = v;
+        }
     }
 }
 
-// unsplit step (step2.f / step2qcor.f): x phase q -> t1, y phase updates t1 in place; transverse contributions
-// travel through LDS inside the kernels (classic.hpp), no scratch planes
-static int unsplit_frame(pcl_solver *s, hipStream_t stream) {
-    hipLaunchKernelGGL(copy_frame_kernel, dim3(256), dim3(256), 0, stream, s->q, s->t1, s->cfg.meqn, s->I, s->J,
-                       s->cfg.mbc, s->pitch, s->plane);
+static int unsplit_frame(pcl_solver *s, hipStream_t stream, const int *bc = nullptr, const double *cstate = nullptr) {
+    FrameBc f;
+    for (int k = 0; k < 4; k++) {
+        f.t[k] = bc ? (bc[k] == PCL_BC_CUSTOM ? 100 : bc[k]) : -1;
+        for (int m = 0; m < 8; m++) f.c[k][m] = (bc && bc[k] == PCL_BC_CUSTOM && cstate) ? cstate[k * PCL_MAX_RP_PARAMS + m] : 0.0;
+    }
+    hipLaunchKernelGGL(frame_kernel, dim3(256), dim3(256), 0, stream, s->q, s->t1, s->cfg.meqn, s->I, s->J, s->cfg.mbc,
+                       s->pitch, s->plane, f);
     HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
@@ -968,31 +1002,25 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     // Decomposed unsplit 2-D step: the ghost frame (exchange, then the physical BCs) is built on the halo stream while
     // the x phase runs the tiles that read no ghost cell; the rim tiles follow on the halo stream, the y phase (it reads
     // every cell of qold and of the x-phase result) after the join.  PCL_HALO_OVERLAP=2: the same launches on one
-    // stream with the interior tiles strictly BEFORE the frame (race check, as for the dim-split step).
-    const bool overlapped_u = s->halo.active && s->cfg.ndim == 2 && s->cfg.method[2] >= 0 && s->overlap && s->sel == 0;
-    if (overlapped_u) {
+    // stream with the interior tiles strictly BEFORE the frame (race check, as for the dim-split step).  Without a
+    // communicator the same code runs on one stream: ghost frame (one launch for all four sides), x phase, y phase.
+    if (s->cfg.ndim == 2 && s->cfg.method[2] >= 0 && s->sel == 0) {
         std::string err;
-        const bool seq = s->overlap == 2;
+        const bool ov = s->halo.active && s->overlap;    // else: everything on the solver stream, in order
+        const bool seq = !ov || s->overlap == 2;
         const hipStream_t hs = seq ? s->stream : s->hstream;
         int rc = PCL_OK;
-        if (seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);
-        else {
+        if (ov && seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);
+        else if (ov) {
             HIP_TRY(hipEventRecord(s->ev_h0, s->stream));            // q of the previous step is complete
             HIP_TRY(hipStreamWaitEvent(hs, s->ev_h0, 0));
         }
-        if (!rc && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, hs)) rc = fail(PCL_ECOMM, err);
-        for (int idim = 0; idim < 2 && !rc; idim++)
-            for (int side = 0; side < 2 && !rc; side++) {
-                const int t = bc[2 * idim + side];
-                if (t < 0) continue;
-                rc = t == PCL_BC_CUSTOM
-                         ? bc_launch(s, idim, side, 100, cstate + (2 * idim + side) * PCL_MAX_RP_PARAMS, false, hs)
-                         : bc_launch(s, idim, side, t, nullptr, false, hs);
-            }
-        if (!rc) rc = unsplit_frame(s, hs);
-        if (!rc && !seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);   // interior tiles, concurrent with the frame
-        if (!rc) rc = unsplit_phase(s, 1, dt, 2, hs);                  // rim tiles behind the frame
-        if (!seq) {                                                    // join, also on the error paths
+        if (!rc && s->halo.active && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, hs))
+            rc = fail(PCL_ECOMM, err);
+        if (!rc) rc = unsplit_frame(s, hs, bc, cstate);                // all four sides + the copy to t1: one launch
+        if (!rc && ov && !seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);   // interior tiles, concurrent with the frame
+        if (!rc) rc = unsplit_phase(s, 1, dt, ov ? 2 : 0, hs);        // rim tiles behind the frame (or all tiles)
+        if (ov && !seq) {                                              // join, also on the error paths
             hipError_t he = hipEventRecord(s->ev_h1, hs);
             if (he == hipSuccess) he = hipStreamWaitEvent(s->stream, s->ev_h1, 0);
             if (!rc && he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream join: ") + hipGetErrorString(he));

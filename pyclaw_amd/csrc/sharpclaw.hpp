@@ -150,7 +150,11 @@ template <class RP, int IXY, bool CAPA, int LIM>
 __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     constexpr int NAUX = RP::NAUX, PAUX = MEQN + (CAPA ? 1 : 0);   // planes: q, capa, the RP's aux components
-    constexpr int NP = PAUX + NAUX;
+    // x pass: the lanes of a strip run along i, so each lane reads its own aux values straight from HBM (coalesced)
+    // and the tile holds only q (+ capa): 40-48 KB instead of 114 KB for the sphere solver's 9 components, i.e.
+    // 3-4 workgroups per CU instead of 1.  y pass: aux goes through the tile like q (the transposition).
+    constexpr int NAUX_LDS = IXY == 1 ? 0 : NAUX;
+    constexpr int NP = PAUX + NAUX_LDS;
     constexpr int PLANE = T_ACROSS_S * WAVE;
     using Cell = typename RP::Cell;
     __shared__ double tile[NP * PLANE];
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
         for (int m = 0; m < MEQN; m++) tile[stile_at<IXY>(m, al, ac)] = a.qin[m * a.plane + g];
         if constexpr (CAPA) tile[stile_at<IXY>(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
 #pragma unroll
-        for (int m = 0; m < NAUX; m++) tile[stile_at<IXY>(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + g];
+        for (int m = 0; m < NAUX_LDS; m++) tile[stile_at<IXY>(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + g];
     }
     __syncthreads();
 
@@ -219,8 +223,15 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
 
         // both edge states carry the cell's own aux values (flux1.f90:125 passes aux,aux)
         double auxv[NAUX > 0 ? NAUX : 1];
+        if constexpr (IXY == 1 && NAUX > 0) {
+            const int cc = ca < n_along ? ca : n_along - 1;
+            const long g = (long)gb * a.pitch + cc;
 #pragma unroll
-        for (int m = 0; m < NAUX; m++) auxv[m] = tile[stile_at<IXY>(PAUX + m, lane, ac)];
+            for (int m = 0; m < NAUX; m++) auxv[m] = a.aux[aux_idx<RP, 1>(m) * a.plane + g];
+        } else {
+#pragma unroll
+            for (int m = 0; m < NAUX; m++) auxv[m] = tile[stile_at<IXY>(PAUX + m, lane, ac)];
+        }
         Cell cl, cr;
         if constexpr (NAUX > 0) {
             cl = RP::template precell<IXY>(ql, a.par, auxv);
