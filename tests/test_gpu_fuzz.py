@@ -1,0 +1,152 @@
+"""
+GPU: seeded randomized parity sweep.  Shapes are drawn so that every tile-edge case of the kernels is met many
+times (sizes around multiples of 60 / 58 / 240 cells and of 14 / 16 rows, tiny grids, long thin grids), with random
+limiters, orders, transverse settings, capacity function on/off and patchy states (constant patches next to random
+ones, so the jump-free shortcut and the absent-family skips switch on and off inside one grid).  Everything through
+the f2py-shaped C ABI against the C oracle, bit for bit, Courant number included.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+
+
+def _lib():
+    from pyclaw_amd import _lib as L
+    return L
+
+
+EDGES = [1, 2, 3, 13, 14, 15, 16, 17, 28, 29, 57, 58, 59, 60, 61, 62, 63, 64, 65, 116, 119, 120, 121, 122, 179, 180,
+         181, 239, 240, 241, 242, 243, 244, 245, 300, 479, 480, 481, 484]
+
+
+def draw_shape(rng, big=520):
+    pick = lambda: int(rng.choice(EDGES)) if rng.random() < 0.7 else int(rng.integers(1, big))
+    mx, my = pick(), pick()
+    if mx * my > 60000:          # keep the oracle fast
+        if rng.random() < 0.5:
+            my = max(1, 60000 // mx)
+        else:
+            mx = max(1, 60000 // my)
+    return mx, my
+
+
+def patchy_euler(rng, shape):
+    q = np.empty((5,) + shape, order="F")
+    rho = 0.5 + rng.random(shape)
+    u = 1.5 * (rng.random(shape) - 0.5)
+    v = 1.5 * (rng.random(shape) - 0.5)
+    p = 0.3 + rng.random(shape)
+    q[0] = rho
+    q[1] = rho * u
+    q[2] = rho * v
+    q[3] = p / 0.4 + 0.5 * rho * (u * u + v * v)
+    q[4] = rng.random(shape)
+    # constant patches (whole wavefronts without a jump) and a tracer-free band
+    for _ in range(int(rng.integers(0, 4))):
+        i0, j0 = int(rng.integers(0, shape[0])), int(rng.integers(0, shape[1]))
+        i1, j1 = i0 + int(rng.integers(1, 200)), j0 + int(rng.integers(1, 200))
+        q[:, i0:i1, j0:j1] = q[:, i0:i0 + 1, j0:j0 + 1]
+    if rng.random() < 0.5:
+        q[4] = 0.0
+    return q
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_step2ds(coracle, seed):
+    L = _lib()
+    rng = np.random.default_rng(7000 + seed)
+    mx, my = draw_shape(rng)
+    mbc = 2
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    q0 = patchy_euler(rng, shape)
+    capa = rng.random() < 0.3
+    aux = np.asfortranarray(0.5 + rng.random((1,) + shape)) if capa else None
+    par = np.array([1.4, 0.4])
+    mth = rng.integers(0, 6, size=5).astype(np.int32)
+    order = int(rng.integers(1, 3))
+    method = np.array([1, order, -1, 0, 0, 1 if capa else 0, 1 if capa else 0], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 0.7 / my, 0.04 / max(mx, my)
+    for ids in (1, 2):
+        ref = q0.copy("F")
+        _, cfl_ref = coracle.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), ref, aux,
+                                     dx, dy, dt, method, mth, ids)
+        out = q0.copy("F")
+        cfl = C.c_double()
+        L.check(L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 1 if capa else 0, mbc, mx, my, L.d(q0), L.d(out),
+                                    L.d(aux) if capa else None, dx, dy, dt, L.i(method), L.i(mth),
+                                    C.cast(C.byref(cfl), L.dp), ids))
+        assert np.array_equal(out, ref), "seed %d %dx%d ids %d capa %s: max diff %g" % (
+            seed, mx, my, ids, capa, np.nanmax(np.abs(out - ref)))
+        assert cfl.value == cfl_ref
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_step2_unsplit(coracle, seed):
+    L = _lib()
+    rng = np.random.default_rng(8000 + seed)
+    mx, my = draw_shape(rng)
+    mbc = 2
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    q0 = patchy_euler(rng, shape)
+    capa = rng.random() < 0.4
+    aux = np.asfortranarray(0.5 + rng.random((1,) + shape)) if capa else None
+    par = np.array([1.4, 0.4])
+    mth = rng.integers(0, 6, size=5).astype(np.int32)
+    order, trans = int(rng.integers(1, 3)), int(rng.integers(0, 3))
+    method = np.array([1, order, trans, 0, 0, 1 if capa else 0, 1 if capa else 0], dtype=np.int32)
+    dx, dy, dt = 1.0 / mx, 0.7 / my, 0.03 / max(mx, my)
+    ref = q0.copy("F")
+    _, cfl_ref = coracle.step2(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), ref, aux, dx, dy, dt,
+                               method, mth)
+    out = q0.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 1 if capa else 0, mbc, mx, my, L.d(q0), L.d(out),
+                              L.d(aux) if capa else None, dx, dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
+    assert np.array_equal(out[inner], ref[inner]), "seed %d %dx%d order %d trans %d capa %s: max diff %g" % (
+        seed, mx, my, order, trans, capa, np.nanmax(np.abs(out[inner] - ref[inner])))
+    assert cfl.value == cfl_ref
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_sharp_flux2(coracle, seed):
+    L = _lib()
+    rng = np.random.default_rng(9000 + seed)
+    mx, my = draw_shape(rng, big=300)
+    mbc = 3
+    shape = (mx + 2 * mbc, my + 2 * mbc)
+    q = patchy_euler(rng, shape)
+    lim = int(rng.choice([2, 3]))
+    par = [1.4, 0.4]
+    dx, dy, dt = 1.0 / mx, 0.8 / my, 0.02 / max(mx, my)
+    ref, cfl_ref = coracle.sharp_flux2(O.RP_EULER5_2D, par, lim, 5, 0, mbc, mx, my, q, None, dx, dy, dt)
+    cfg = L.Config()
+    cfg.ndim = 2
+    cfg.n[0], cfg.n[1] = mx, my
+    cfg.d[0], cfg.d[1] = dx, dy
+    cfg.mbc = mbc
+    cfg.meqn, cfg.mwaves, cfg.rp = 5, 5, 11
+    cfg.method[1] = 2
+    cfg.rp_params[0], cfg.rp_params[1] = 1.4, 0.4
+    cfg.kind = 1
+    cfg.lim_type = lim
+    h = C.c_void_p()
+    L.check(L.lib().pcl_create(C.byref(cfg), C.byref(h)))
+    try:
+        L.check(L.lib().pcl_put_q(h, L.d(q), 1))
+        cfl = C.c_double()
+        L.check(L.lib().pcl_sharp_dq(h, dt, C.cast(C.byref(cfl), L.dp)))
+        L.check(L.lib().pcl_select(h, 3))
+        out = np.zeros_like(q)
+        L.check(L.lib().pcl_get_q(h, L.d(out), 1))
+    finally:
+        L.lib().pcl_destroy(h)
+    inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
+    same = (out[inner] == ref[inner]) | (np.isnan(out[inner]) & np.isnan(ref[inner]))
+    assert same.all(), "seed %d %dx%d lim %d: %d cells differ" % (seed, mx, my, lim, (~same).sum())
+    assert cfl.value == cfl_ref or (np.isnan(cfl.value) and np.isnan(cfl_ref))
