@@ -188,7 +188,8 @@ def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=T
     return claw
 
 
-def acoustics1D(pyclaw, mx=100, solver_type='classic', lim_type=2, time_integrator='SSP104'):
+def acoustics1D(pyclaw, mx=100, solver_type='classic', lim_type=2, time_integrator='SSP104', weno_order=5,
+                math='exact'):
     """test/acoustics/1d/homogeneous/acoustics.py: returns the one-period L1 error."""
     if solver_type == 'classic':
         solver = pyclaw.ClawSolver1D()
@@ -196,6 +197,8 @@ def acoustics1D(pyclaw, mx=100, solver_type='classic', lim_type=2, time_integrat
         solver = pyclaw.SharpClawSolver1D()
         solver.lim_type = lim_type
         solver.time_integrator = time_integrator
+        solver.weno_order = weno_order
+    solver.math = math
     solver.rp = pyclaw.riemann.rp_acoustics_1d
     x = pyclaw.Dimension('x', 0.0, 1.0, mx)
     grid = pyclaw.Grid(x)

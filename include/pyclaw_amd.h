@@ -115,7 +115,8 @@ typedef struct pcl_config {
     int math;                       /* PCL_MATH_*                                          */
     int kind;                       /* PCL_KIND_CLASSIC | PCL_KIND_SHARPCLAW               */
     int lim_type;                   /* SharpClaw: 1 = tvd2 (reconstruct.f90:568-625; mthlim per COMPONENT),     */
-                                    /*            2 = WENO5 (PyWENO form), 3 = legacy WENO5                      */
+                                    /*            2 = PyWENO form (weno.f90), order 2*mbc-1: mbc = 3..9 is      */
+                                    /*                weno_order 5..17 (sharpclaw.py:479), 3 = legacy WENO5     */
 } pcl_config;
 
 /* ---- library ---------------------------------------------------------------------- */
@@ -172,7 +173,8 @@ int pcl_step3(int rp, const double *rp_params, int meqn, int mwaves, int maux, i
 
 /* sharpclaw1.flux1(q,aux,dt,t,ixy,mx,mbc,maxnx) -> (dq,cfl)   1d/sharpclaw/flux1.f90, sharpclaw.py:385
  * sharpclaw2.flux2(q,aux,dt,t,mbc,maxm,mx,my)   -> (dq,cfl)   2d/sharpclaw/flux2.f90:2, sharpclaw.py:558
- * q and dq are (meqn, mx+2mbc[, my+2mbc]) with mbc = 3 (weno_order 5); dq's interior receives
+ * q and dq are (meqn, mx+2mbc[, my+2mbc]) with mbc = (weno_order+1)/2 = 3..9 (clawparams.weno_order is
+ * implied by mbc: lim_type 2 with mbc = k runs weno(2k-1); lim_type 1 and 3 take mbc = 3); dq's interior receives
  * dt*dq/dt, its ghost cells are zeroed.  The F90 module state the reference sets through
  * clawparams/workspace/reconstruct (lim_type, mcapa, dx, mwaves) is passed explicitly. */
 /* clawparams.mthlim, part of the F90 module state the reference sets before calling flux1/flux2

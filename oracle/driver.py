@@ -104,10 +104,11 @@ class Problem:
         self.qcor = False                  # app-local step2qcor.f in place of step2.f (shallow water on the sphere)
         self.solver_type = 'classic'
         self.lim_type = 2
+        self.weno_order = 5
         self.time_integrator = 'SSP104'
         self.__dict__.update(kw)
         if self.solver_type == 'sharpclaw' and 'mbc' not in kw:
-            self.mbc = 3                                   # (weno_order+1)/2, sharpclaw.py:479
+            self.mbc = (self.weno_order + 1) // 2           # sharpclaw.py:479
         self.ndim = self.q.ndim - 1
         self.t = 0.0
         self.dt = self.dt_initial
@@ -279,6 +280,8 @@ def sharp_dq(p, backend, q, t):
     inner = (slice(None),) + (slice(mbc, -mbc),) * p.ndim
     p.qbc[inner] = q
     fill_ghosts(p.qbc, mbc, p.bc_lower, p.bc_upper, p.user_bc_lower, p.user_bc_upper, t)
+    if hasattr(backend, "set_weno_order"):
+        backend.set_weno_order(p.weno_order)               # clawparams.weno_order (sharpclaw.py:263)
     if p.ndim == 1:
         dq, cfl = backend.sharp_flux1(p.rp, p.rp_params, p.lim_type, p.mwaves, p.mcapa + 1, mbc, q.shape[1],
                                       p.qbc, p.auxbc, p.d[0], p.dt)

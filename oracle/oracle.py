@@ -96,6 +96,10 @@ class COracle:
                                       C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp]
         L.orc_weno5.restype = None
         L.orc_weno5.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.orc_weno_k.restype = None
+        L.orc_weno_k.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.orc_sharp_set_weno_order.restype = None
+        L.orc_sharp_set_weno_order.argtypes = [C.c_int]
         L.orc_sharp_set_mthlim.restype = None
         L.orc_sharp_set_mthlim.argtypes = [_ip, C.c_int]
         L.orc_sphere_qcor.restype = None
@@ -226,6 +230,17 @@ class COracle:
         if rc:
             raise RuntimeError("oracle sharpclaw: rc=%d" % rc)
         return dq, cfl.value
+
+    def set_weno_order(self, order):
+        """clawparams.weno_order (sharpclaw.py:263): 5 .. 17, odd; mbc must be (order+1)/2"""
+        self.lib.orc_sharp_set_weno_order(int(order))
+
+    def weno_k(self, order, q):
+        meqn, n = q.shape
+        ql = np.zeros((meqn, n), order="F")
+        qr = np.zeros((meqn, n), order="F")
+        self.lib.orc_weno_k(int(order), meqn, n, _d(_f64(q)), _d(ql), _d(qr))
+        return ql, qr
 
     def weno5(self, variant, mbc, q):
         meqn, n = q.shape
@@ -386,7 +401,8 @@ class RefSharp2DEuler:
     def available():
         return os.path.exists(os.path.join(_HERE, "_ref", "libref_sharpclaw2d_euler.so"))
 
-    def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt, mthlim=None):
+    def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt, mthlim=None,
+                    weno_order=5):
         assert rp == RP_EULER5_2D and mcapa == 0
         self.cparam.gamma, self.cparam.gamma1 = float(par[0]), float(par[1])
         meqn = q.shape[0]
@@ -394,7 +410,7 @@ class RefSharp2DEuler:
         dxs = np.array([dx, dy])
         mth = np.array(mthlim if mthlim is not None else [1] * mwaves, dtype=np.int32)
         self.lib.sc_setup(C.c_int(2), C.c_int(meqn), C.c_int(mwaves), C.c_int(mbc), C.c_int(maxnx),
-                          C.c_int(lim_type), C.c_int(5), C.c_int(0), C.c_int(0), _d(dxs), _i(mth))
+                          C.c_int(lim_type), C.c_int(weno_order), C.c_int(0), C.c_int(0), _d(dxs), _i(mth))
         dq = np.zeros(q.shape, order="F")
         q1d = np.zeros((meqn, maxnx + 2 * mbc), order="F")
         dq1d = np.zeros((meqn, maxnx + 2 * mbc), order="F")

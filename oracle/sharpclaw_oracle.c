@@ -71,6 +71,63 @@ static void weno5_pyweno(const double *q, double *ql, double *qr, int meqn, int 
         }
 }
 
+/* weno.f90: weno7 ... weno17 (and weno5 again, k = 3): the generated subroutines all have one shape -- for the k
+ * stencils r = 0..k-1 (cells i-r .. i-r+k-1) the smoothness indicator as a sum over a <= b of ((C*q_a)*q_b) in
+ * lexicographic order, the two sets of nonlinear weights (w / (sigma + 1e-36)**2, normalised by their running sum),
+ * the 2k candidate values and their weighted sums, every sum left-associated in the printed order.  The coefficients
+ * are derived from first principles by tools/gen_weno.py (and compared there with the literals of the reference's
+ * file); like the Fortran's REAL*4 literals they are float32-rounded.  order = 2k-1, mbc = k. */
+#include "weno_tables.h"
+static int orc_weno_order = 5;
+void orc_sharp_set_weno_order(int order) { orc_weno_order = order; }
+static void weno_pyweno_k(int k, const double *q, double *ql, double *qr, int meqn, int n)
+{
+    const int t = k - 3;
+    const double eps = F32(1.0e-36);
+    for (int i = k; i <= n - (k - 1); i++)          /* every index whose (2k-1)-point stencil is in range */
+        for (int m = 0; m < meqn; m++) {
+            double sigma[9], oml[9], omr[9];
+            for (int r = 0; r < k; r++) {
+                double sg = 0.0;
+                int first = 1;
+                for (int a = 0; a < k; a++)
+                    for (int b = a; b < k; b++) {
+                        const double term = (WENO_SIG[t][r][a][b] * Q(m, i - r + a)) * Q(m, i - r + b);
+                        sg = first ? term : sg + term;
+                        first = 0;
+                    }
+                sigma[r] = sg;
+            }
+            double acc = 0.0;
+            for (int r = 0; r < k; r++) {
+                const double tt = sigma[r] + eps;
+                oml[r] = WENO_WL[t][r] / (tt * tt);
+                acc = acc + oml[r];
+            }
+            for (int r = 0; r < k; r++) oml[r] = oml[r] / acc;
+            acc = 0.0;
+            for (int r = 0; r < k; r++) {
+                const double tt = sigma[r] + eps;
+                omr[r] = WENO_WR[t][r] / (tt * tt);
+                acc = acc + omr[r];
+            }
+            for (int r = 0; r < k; r++) omr[r] = omr[r] / acc;
+            double fs0 = 0.0, fs1 = 0.0;
+            for (int r = 0; r < k; r++) {
+                double fl = 0.0, fr = 0.0;
+                for (int j = 0; j < k; j++) {
+                    const double tl = WENO_CL[t][r][j] * Q(m, i - r + j), tr = WENO_CR[t][r][j] * Q(m, i - r + j);
+                    fl = j == 0 ? tl : fl + tl;
+                    fr = j == 0 ? tr : fr + tr;
+                }
+                fs0 = r == 0 ? oml[r] * fl : fs0 + oml[r] * fl;
+                fs1 = r == 0 ? omr[r] * fr : fs1 + omr[r] * fr;
+            }
+            QL(m, i) = fs0;
+            QR(m, i) = fs1;
+        }
+}
+
 /* reconstruct.f90:120-185.  uu(1,i) -> qr(i-1), uu(2,i) -> ql(i); i = mbc .. mx2-mbc+1 */
 static void weno5_legacy(const double *q, double *ql, double *qr, int meqn, int mx2, int mbc)
 {
@@ -169,8 +226,12 @@ static int flux1(int ndim, int rp, const double *par, int lim_type, int ixy, int
     /* the Fortran indexes the slice 1..maxnx+2mbc inside weno: i_weno = i_cell + mbc */
     if (lim_type == 1)
         tvd2(q, ql, qr, meqn, n);
-    else if (lim_type == 2)
+    else if (lim_type == 2 && orc_weno_order == 5)
         weno5_pyweno(q, ql, qr, meqn, n, 3, n - 2);     /* every index whose 5-point stencil is in range */
+    else if (lim_type == 2) {                           /* reconstruct.f90:96-114: weno_order 7 .. 17 */
+        if (orc_weno_order < 5 || orc_weno_order > 17 || !(orc_weno_order & 1) || mbc < (orc_weno_order + 1) / 2) return -3;
+        weno_pyweno_k((orc_weno_order + 1) / 2, q, ql, qr, meqn, n);
+    }
     else if (lim_type == 3)
         weno5_legacy(q, ql, qr, meqn, n, mbc);
     else
@@ -290,6 +351,12 @@ int orc_sharp_flux1(int rp, const double *par, int lim_type, int meqn, int mwave
     orc_aux1d = NULL;
     free(dtdx); free(work);
     return rc;
+}
+
+/* the generic form, any order 5..17 (tests: k = 3 == the hand-written weno5 above) */
+void orc_weno_k(int order, int meqn, int n, const double *q, double *ql, double *qr)
+{
+    weno_pyweno_k((order + 1) / 2, q, ql, qr, meqn, n);
 }
 
 void orc_weno5(int variant, int meqn, int n, int mbc, const double *q, double *ql, double *qr)

@@ -249,60 +249,86 @@ int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err) {
 
 // SharpClaw: dq of one direction (x writes dq, y accumulates)
 namespace {
-template <class RP, int IXY> int launch_sharp_t(const SweepLaunch &l, std::string &err) {
+template <class RP, int IXY, int K> int launch_sharp_k(const SweepLaunch &l, std::string &err) {
     SweepArgs a = l.a;
+    constexpr int SH = K, SS = sstrip(K);
     if (IXY == 1 && a.sub != 0) {
         // x-pass tiles whose 16 rows x 64 cells lie inside the interior: rows 16*tb .. +15 within [mbc, mbc+my), cells
-        // mbc-3+58*ta .. +63 within [mbc, mbc+mx)
+        // mbc-K+SS*ta .. +63 within [mbc, mbc+mx)
         a.box[0] = (a.mbc + T_ACROSS_S - 1) / T_ACROSS_S;
         a.box[1] = a.mbc + a.my >= T_ACROSS_S ? (a.mbc + a.my - T_ACROSS_S) / T_ACROSS_S + 1 : 0;
         a.box[2] = 1;
-        a.box[3] = a.mx >= WAVE - SHALO ? (a.mx - (WAVE - SHALO)) / SSTRIP + 1 : 0;
+        a.box[3] = a.mx >= WAVE - SH ? (a.mx - (WAVE - SH)) / SS + 1 : 0;
     } else a.sub = 0;
     const int n_across = IXY == 1 ? a.J : a.I + (LINE - a.mbc);
     const int m_along = IXY == 1 ? a.mx : a.my;
     const int ntiles_across = (n_across + T_ACROSS_S - 1) / T_ACROSS_S;
-    const int ntiles_along = (m_along + SSTRIP - 1) / SSTRIP;
+    const int ntiles_along = (m_along + SS - 1) / SS;
     const dim3 grid((unsigned)ntiles_across * (unsigned)ntiles_along);
     const bool capa = a.mcapa > 0;
 #define PCL_SHARP_LAUNCH(CAPA_, LIM_)                                                                  \
-    hipLaunchKernelGGL((sharp_kernel<RP, IXY, CAPA_, LIM_>), grid, dim3(256), 0, l.stream, a, ntiles_across, \
+    hipLaunchKernelGGL((sharp_kernel<RP, IXY, CAPA_, LIM_, K>), grid, dim3(256), 0, l.stream, a, ntiles_across, \
                        ntiles_along)
-    if (l.lim_type == 1) { if (capa) PCL_SHARP_LAUNCH(true, 1); else PCL_SHARP_LAUNCH(false, 1); }
-    else if (l.lim_type == 2) { if (capa) PCL_SHARP_LAUNCH(true, 2); else PCL_SHARP_LAUNCH(false, 2); }
-    else if (l.lim_type == 3) { if (capa) PCL_SHARP_LAUNCH(true, 3); else PCL_SHARP_LAUNCH(false, 3); }
-    else { err = "SharpClaw: lim_type must be 1 (tvd2), 2 (WENO5) or 3 (legacy WENO5)"; return PCL_EINVAL; }
+    if constexpr (K > 3) {
+        if (l.lim_type != 2) { err = "SharpClaw: weno_order > 5 needs lim_type 2"; return PCL_EINVAL; }
+        if (capa) PCL_SHARP_LAUNCH(true, 2); else PCL_SHARP_LAUNCH(false, 2);
+    } else {
+        if (l.lim_type == 1) { if (capa) PCL_SHARP_LAUNCH(true, 1); else PCL_SHARP_LAUNCH(false, 1); }
+        else if (l.lim_type == 2) { if (capa) PCL_SHARP_LAUNCH(true, 2); else PCL_SHARP_LAUNCH(false, 2); }
+        else if (l.lim_type == 3) { if (capa) PCL_SHARP_LAUNCH(true, 3); else PCL_SHARP_LAUNCH(false, 3); }
+        else { err = "SharpClaw: lim_type must be 1 (tvd2), 2 (WENO5) or 3 (legacy WENO5)"; return PCL_EINVAL; }
+    }
 #undef PCL_SHARP_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PCL_OK : hip_fail(err, "sharp launch", e);
+}
+// mbc = (weno_order+1)/2 (sharpclaw.py:479).  HIGH = this solver also has the kernels of weno_order 7..17 (mbc 4..9):
+// the 1-D solvers, 2-D advection, acoustics and Euler; the others are built for mbc = 3 only.
+template <class RP, int IXY, bool HIGH = false> int launch_sharp_t(const SweepLaunch &l, std::string &err) {
+    if (l.a.mbc == 3) return launch_sharp_k<RP, IXY, 3>(l, err);
+    if constexpr (HIGH) {
+        switch (l.a.mbc) {
+        case 4: return launch_sharp_k<RP, IXY, 4>(l, err);
+        case 5: return launch_sharp_k<RP, IXY, 5>(l, err);
+        case 6: return launch_sharp_k<RP, IXY, 6>(l, err);
+        case 7: return launch_sharp_k<RP, IXY, 7>(l, err);
+        case 8: return launch_sharp_k<RP, IXY, 8>(l, err);
+        case 9: return launch_sharp_k<RP, IXY, 9>(l, err);
+        }
+        err = "SharpClaw: mbc must be 3..9 (weno_order 5..17)";
+        return PCL_EINVAL;
+    }
+    err = "SharpClaw: this Riemann solver is built for weno_order 5 (mbc 3) only; orders 7..17 exist for the 1-D solvers "
+          "and for advection_2d, acoustics_2d, euler_5wave_2d";
+    return PCL_EINVAL;
 }
 }  // namespace
 
 int launch_sharp(const SweepLaunch &l, std::string &err) {
     const int rp = l.rp;
     if (l.ndim == 1) {
-        if (rp == PCL_RP_ADVECTION_1D) return launch_sharp_t<Advection1D, 1>(l, err);
-        if (rp == PCL_RP_ACOUSTICS_1D) return launch_sharp_t<Acoustics1D, 1>(l, err);
-        if (rp == PCL_RP_BURGERS_1D) return launch_sharp_t<Burgers1D, 1>(l, err);
-        if (rp == PCL_RP_EULER_1D) return launch_sharp_t<Euler1D, 1>(l, err);
-        if (rp == PCL_RP_SHALLOW_1D) return launch_sharp_t<Shallow1D, 1>(l, err);
-        if (rp == PCL_RP_ADVECTION_COLOR_1D) return launch_sharp_t<AdvectionColor1D, 1>(l, err);
+        if (rp == PCL_RP_ADVECTION_1D) return launch_sharp_t<Advection1D, 1, true>(l, err);
+        if (rp == PCL_RP_ACOUSTICS_1D) return launch_sharp_t<Acoustics1D, 1, true>(l, err);
+        if (rp == PCL_RP_BURGERS_1D) return launch_sharp_t<Burgers1D, 1, true>(l, err);
+        if (rp == PCL_RP_EULER_1D) return launch_sharp_t<Euler1D, 1, true>(l, err);
+        if (rp == PCL_RP_SHALLOW_1D) return launch_sharp_t<Shallow1D, 1, true>(l, err);
+        if (rp == PCL_RP_ADVECTION_COLOR_1D) return launch_sharp_t<AdvectionColor1D, 1, true>(l, err);
     } else if (l.ids == 1) {
-        if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 1>(l, err);
-        if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 1>(l, err);
+        if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 1, true>(l, err);
+        if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 1, true>(l, err);
         if (rp == PCL_RP_SHALLOW_2D) return launch_sharp_t<Shallow2D, 1>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch_sharp_t<VcAcoustics2D, 1>(l, err);
         if (rp == PCL_RP_VC_ADVECTION_2D) return launch_sharp_t<VcAdvection2D, 1>(l, err);
         if (rp == PCL_RP_SHALLOW_SPHERE_2D) return launch_sharp_t<ShallowSphere, 1>(l, err);
-        if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 1>(l, err);
+        if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 1, true>(l, err);
     } else {
-        if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 2>(l, err);
-        if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 2>(l, err);
+        if (rp == PCL_RP_ACOUSTICS_2D) return launch_sharp_t<Acoustics2D, 2, true>(l, err);
+        if (rp == PCL_RP_ADVECTION_2D) return launch_sharp_t<Advection2D, 2, true>(l, err);
         if (rp == PCL_RP_SHALLOW_2D) return launch_sharp_t<Shallow2D, 2>(l, err);
         if (rp == PCL_RP_VC_ACOUSTICS_2D) return launch_sharp_t<VcAcoustics2D, 2>(l, err);
         if (rp == PCL_RP_VC_ADVECTION_2D) return launch_sharp_t<VcAdvection2D, 2>(l, err);
         if (rp == PCL_RP_SHALLOW_SPHERE_2D) return launch_sharp_t<ShallowSphere, 2>(l, err);
-        if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 2>(l, err);
+        if (rp == PCL_RP_EULER5_2D) return launch_sharp_t<Euler5, 2, true>(l, err);
     }
     err = "Riemann solver id does not match the grid dimension";
     return PCL_EINVAL;

@@ -592,8 +592,11 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (cfg->ndim < 1 || cfg->ndim > 3) return fail(PCL_EINVAL, "ndim must be 1, 2 or 3");
     if (cfg->kind == PCL_KIND_CLASSIC && cfg->mbc != 2)
         return fail(PCL_EINVAL, "classic kernels need mbc == 2 (reference default)");
-    if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->mbc != 3)
-        return fail(PCL_EINVAL, "SharpClaw kernels implement weno_order 5: mbc == 3");
+    // mbc = (weno_order+1)/2 (sharpclaw.py:479): 3 for tvd2 / WENO5 / legacy WENO5, 4..9 = weno_order 7..17 (lim_type 2)
+    if (cfg->kind == PCL_KIND_SHARPCLAW && (cfg->mbc < 3 || cfg->mbc > 9))
+        return fail(PCL_EINVAL, "SharpClaw: mbc = (weno_order+1)/2 must be 3..9 (weno_order 5..17)");
+    if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->mbc > 3 && cfg->lim_type != 2)
+        return fail(PCL_EINVAL, "SharpClaw: weno_order > 5 (mbc > 3) exists for lim_type 2 only");
     if (cfg->kind != PCL_KIND_CLASSIC && cfg->kind != PCL_KIND_SHARPCLAW) return fail(PCL_EINVAL, "unknown solver kind");
     if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->lim_type != 1 && cfg->lim_type != 2 && cfg->lim_type != 3)
         return fail(PCL_EINVAL, "SharpClaw: lim_type must be 1 (tvd2), 2 (WENO5) or 3 (legacy WENO5)");

@@ -15,13 +15,14 @@
 // cell between its own edge states (flux1.f90:166-187).
 #pragma once
 #include "classic.hpp"
+#include "weno_tables.hpp"
 
 namespace pcl {
 namespace PCL_NS {
 
 constexpr int T_ACROSS_S = 16;
-constexpr int SHALO = 3;
-constexpr int SSTRIP = WAVE - 2 * SHALO;  // 58 cells updated per strip
+// halo of a strip = mbc = (weno_order+1)/2 (sharpclaw.py:479): 3 for WENO5 / tvd2, up to 9 for WENO17
+constexpr int sstrip(int halo) { return WAVE - 2 * halo; }   // cells updated per strip: 58 ... 46
 
 // REAL*4 literals of the generated Fortran, promoted to double (weno.f90 has no d0 exponents)
 #define PCL_F32(x) ((double)(float)(x))
@@ -69,6 +70,60 @@ __device__ __forceinline__ void weno5_pyweno(double qm2, double qm1, double q0, 
     const double fr5 = f033 * qm2 + f116 * qm1 + f183 * q0;
     ql = omega0 * fr0 + omega1 * fr1 + omega2 * fr2;
     qr = omega3 * fr3 + omega4 * fr4 + omega5 * fr5;
+}
+
+// weno.f90: weno7 ... weno17 (K = 4..9; K = 3 is the hand-unrolled weno5 above): for the K stencils r = 0..K-1 (cells
+// i-r .. i-r+K-1) the smoothness indicator as a sum over a <= b of ((C*q_a)*q_b) in lexicographic order, the two sets
+// of nonlinear weights w / (sigma + 1e-36)**2 normalised by their running sum, the 2K candidate values and their
+// weighted sums, every sum left-associated in the printed order.  Tables: weno_tables.hpp (tools/gen_weno.py).
+// qs[j] = q(i - (K-1) + j).  The 2K + 2K divisions share K + 2 reciprocals (same correctly rounded quotients).
+template <int K>
+__device__ __forceinline__ void weno_pyweno_k(const double (&qs)[2 * K - 1], double &ql, double &qr) {
+    // (Conditioning: the coefficients of the high orders reach 1e5 with alternating signs, so on smooth data the
+    // smoothness sums are rounding noise and the weights -- w / (sigma + 1e-36)^2 -- follow that noise.  Bit-identical
+    // to the reference in exact mode; in fast mode, or for inputs that differ in the last digit, the stencils are
+    // weighted differently: another valid WENO result, not a nearby one.  See DESIGN 4.3.)
+    constexpr int T = K - 3;
+    constexpr double eps = PCL_F32(1.0e-36);
+    Recip by_d[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        double sg = 0.0;
+#pragma unroll
+        for (int a = 0; a < K; a++)
+#pragma unroll
+            for (int b = a; b < K; b++) {
+                const double term = (WENO_SIG[T][r][a][b] * qs[K - 1 - r + a]) * qs[K - 1 - r + b];
+                sg = (a == 0 && b == 0) ? term : sg + term;
+            }
+        const double t = sg + eps;
+        by_d[r] = Recip(t * t);
+    }
+    double oml[K], omr[K], accl = 0.0, accr = 0.0;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        oml[r] = by_d[r].div(WENO_WL[T][r]);
+        omr[r] = by_d[r].div(WENO_WR[T][r]);
+        accl = r == 0 ? oml[r] : accl + oml[r];
+        accr = r == 0 ? omr[r] : accr + omr[r];
+    }
+    const Recip by_l(accl), by_r(accr);
+    double fs0 = 0.0, fs1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        double fl = 0.0, fr = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const double tl = WENO_CL[T][r][j] * qs[K - 1 - r + j], tr = WENO_CR[T][r][j] * qs[K - 1 - r + j];
+            fl = j == 0 ? tl : fl + tl;
+            fr = j == 0 ? tr : fr + tr;
+        }
+        const double wl = by_l.div(oml[r]), wr = by_r.div(omr[r]);
+        fs0 = r == 0 ? wl * fl : fs0 + wl * fl;
+        fs1 = r == 0 ? wr * fr : fs1 + wr * fr;
+    }
+    ql = fs0;
+    qr = fs1;
 }
 
 // reconstruct.f90:147-176: the interface value uu(m1,i) between cells i-1 and i.
@@ -146,9 +201,11 @@ template <int IXY> __device__ __forceinline__ int stile_at(int m, int al, int ac
 #ifndef PCL_SHARP_OCC
 #define PCL_SHARP_OCC 4     // workgroups per CU the register budget is sized for (A/B: build with -DPCL_SHARP_OCC=3)
 #endif
-template <class RP, int IXY, bool CAPA, int LIM>
+template <class RP, int IXY, bool CAPA, int LIM, int K = 3>
 __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
+    constexpr int SHALO = K, SSTRIP = sstrip(K);      // a.mbc == K (checked by the launcher)
+    static_assert(K == 3 || LIM == 2, "orders above 5 exist for the PyWENO form only");
     constexpr int NAUX = RP::NAUX, PAUX = MEQN + (CAPA ? 1 : 0);   // planes: q, capa, the RP's aux components
     // x pass: the lanes of a strip run along i, so each lane reads its own aux values straight from HBM (coalesced)
     // and the tile holds only q (+ capa): 40-48 KB instead of 114 KB for the sphere solver's 9 components, i.e.
@@ -213,7 +270,16 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
             const double qm2 = tile[stile_at<IXY>(m, lm2, ac)], qm1 = tile[stile_at<IXY>(m, lm1, ac)];
             const double q0 = tile[stile_at<IXY>(m, lane, ac)];
             const double qp1 = tile[stile_at<IXY>(m, lp1, ac)], qp2 = tile[stile_at<IXY>(m, lp2, ac)];
-            if (LIM == 1) tvd2_cell(qm1, q0, qp1, a.mthlim[m < MAX_WAVES_K ? m : MAX_WAVES_K - 1], ql[m], qr[m]);
+            if constexpr (K > 3) {
+                double qs[2 * K - 1];
+#pragma unroll
+                for (int j = 0; j < 2 * K - 1; j++) {
+                    int l = lane - (K - 1) + j;
+                    l = l < 0 ? 0 : (l > WAVE - 1 ? WAVE - 1 : l);
+                    qs[j] = tile[stile_at<IXY>(m, l, ac)];
+                }
+                weno_pyweno_k<K>(qs, ql[m], qr[m]);
+            } else if (LIM == 1) tvd2_cell(qm1, q0, qp1, a.mthlim[m < MAX_WAVES_K ? m : MAX_WAVES_K - 1], ql[m], qr[m]);
             else if (LIM == 2) weno5_pyweno(qm2, qm1, q0, qp1, qp2, ql[m], qr[m]);
             else weno5_legacy(qm2, qm1, q0, qp1, qp2, ql[m], qr[m]);
         }

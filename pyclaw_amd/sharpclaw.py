@@ -9,8 +9,9 @@ kernel of csrc/sharpclaw.hpp; the stage registers and the register arithmetic of
 schemes live on the device too (``pcl_rk_op`` evaluates each formula in the order the
 reference's numpy expressions do).
 
-Implemented reconstruction: ``lim_type=2`` with ``weno_order=5`` (the PyWENO-generated ``weno5``,
-float32-rounded literals included) and ``lim_type=3`` (the legacy ``weno5`` of reconstruct.f90,
+Implemented reconstruction: ``lim_type=2`` with ``weno_order`` 5 .. 17 (the PyWENO-generated ``weno5`` ...
+``weno17``, float32-rounded literals included; orders above 5 for the 1-D solvers and advection_2d, acoustics_2d,
+euler_5wave_2d) and ``lim_type=3`` (the legacy ``weno5`` of reconstruct.f90,
 the one the reference's golden ``test/ac_sc_solution`` was produced with); ``char_decomp=0``,
 ``tfluct_solver=False``.
 """
@@ -212,8 +213,11 @@ class SharpClawSolver(Solver):
         """Allocate RK registers and the device solver (sharpclaw.py:302-323, 474-495)."""
         if self.kernel_language not in ('HIP', 'Fortran'):
             raise Exception("Unrecognized value of solver.kernel_language.")
-        if self.weno_order != 5:
-            raise NotImplementedError("pyclaw_amd SharpClaw implements weno_order=5")
+        if self.weno_order not in (5, 7, 9, 11, 13, 15, 17):
+            # reconstruct.f90:112
+            raise Exception("ERROR: weno_order must be an odd number between 5 and 17 (inclusive).")
+        if self.weno_order != 5 and self.lim_type != 2:
+            raise NotImplementedError("weno_order > 5 is a lim_type=2 (PyWENO) reconstruction")
         if self.lim_type not in (1, 2, 3):
             raise NotImplementedError("pyclaw_amd SharpClaw implements lim_type 1 (tvd2), 2 (WENO5) and 3 (legacy WENO5)")
         if self.char_decomp != 0 or self.tfluct_solver:

@@ -8,6 +8,7 @@ under /root/reference, oracle/Makefile) for the paths the reference ships no gol
   ref_sharp_flux2.npz      SharpClaw flux2.f90, lim_type 2 (PyWENO weno5) and 3 (legacy weno5)
   ref_step2_unsplit_capa.npz  step2.f with a capacity function (mcapa = 2), method(3) = 0, 1, 2
   ref_sharp_tvd2.npz       SharpClaw flux2.f90 with lim_type 1 (tvd2), mthlim 1..5
+  ref_sharp_weno_orders.npz  SharpClaw flux2.f90 with lim_type 2 and weno_order 7, 9, ..., 17 (weno.f90)
   ref_sphere_setup.npz     the shallow-sphere app's own setaux.f / qinit.f / src2.f / qcor.f (40 x 20 grid)
 
 Only inputs' SEEDS and the outputs are stored (inputs are regenerated from the seed by the tests).  Run in the
@@ -30,6 +31,24 @@ def euler_state(seed, shape):
     u = 1.5 * (rng.random(shape) - 0.5)
     v = 1.5 * (rng.random(shape) - 0.5)
     p = 0.5 + rng.random(shape)
+    q[0] = rho
+    q[1] = rho * u
+    q[2] = rho * v
+    q[3] = p / 0.4 + 0.5 * rho * (u * u + v * v)
+    q[4] = rng.random(shape)
+    return q
+
+
+def euler_state_mild(seed, shape):
+    """jumps of ~10 % between neighbours: rough enough to exercise every nonlinear weight, mild enough that the
+    reconstructions of order 13 and 15 keep density and pressure positive (on euler_state they do not, and the
+    reference's own result then holds NaNs)"""
+    rng = np.random.default_rng(seed)
+    q = np.empty((5,) + shape, order="F")
+    rho = 1.0 + 0.2 * rng.random(shape)
+    u = 0.3 * (rng.random(shape) - 0.5)
+    v = 0.3 * (rng.random(shape) - 0.5)
+    p = 1.0 + 0.2 * rng.random(shape)
     q[0] = rho
     q[1] = rho * u
     q[2] = rho * v
@@ -124,6 +143,17 @@ def main():
         dq, cfl = sref.sharp_flux2(O.RP_EULER5_2D, PAR, 1, 5, 0, mbc, mx, my, q0, None, dx, dy, dt, mthlim=[lim] * 5)
         out["dq_mth%d" % lim] = dq[:, mbc:-mbc, mbc:-mbc]
     np.savez_compressed(os.path.join(HERE, "ref_sharp_tvd2.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
+
+    # lim_type = 2 with weno_order 7 .. 17 (weno.f90: weno7 ... weno17), mbc = (weno_order+1)/2
+    out = {}
+    for order in (7, 9, 11, 13, 15, 17):
+        g = (order + 1) // 2
+        q0 = euler_state_mild(60 + order, (mx + 2 * g, my + 2 * g))
+        dq, cfl = sref.sharp_flux2(O.RP_EULER5_2D, PAR, 2, 5, 0, g, mx, my, q0, None, dx, dy, dt, weno_order=order)
+        assert np.isfinite(dq).all()
+        out["dq_order%d" % order] = dq[:, g:-g, g:-g]
+        out["cfl_order%d" % order] = cfl
+    np.savez_compressed(os.path.join(HERE, "ref_sharp_weno_orders.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
     print("written:", [f for f in sorted(os.listdir(HERE)) if f.startswith("ref_")])
 
 
