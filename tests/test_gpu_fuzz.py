@@ -150,3 +150,73 @@ def test_fuzz_sharp_flux2(coracle, seed):
     same = (out[inner] == ref[inner]) | (np.isnan(out[inner]) & np.isnan(ref[inner]))
     assert same.all(), "seed %d %dx%d lim %d: %d cells differ" % (seed, mx, my, lim, (~same).sum())
     assert cfl.value == cfl_ref or (np.isnan(cfl.value) and np.isnan(cfl_ref))
+
+
+def _shape3(rng):
+    """one long direction around the strip edges (58..64, 118..125), two short ones; <= 40k cells for the oracle"""
+    long_ = int(rng.choice([1, 2, 59, 60, 61, 62, 63, 64, 65, 119, 120, 121, 124, 125, 181]))
+    a, b = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+    while long_ * a * b > 40000:
+        a, b = max(1, a - 1), max(1, b - 1)
+    n = [long_, a, b]
+    rng.shuffle(n)
+    return tuple(int(v) for v in n)
+
+
+def _state3(rng, n, mbc=2):
+    full = tuple(k + 2 * mbc for k in n)
+    q = np.asfortranarray(rng.standard_normal((4,) + full))
+    if rng.random() < 0.5:          # a quiet half: wavefronts without a jump
+        q[:, : full[0] // 2] = 0.0
+    aux = np.empty((2,) + full, order="F")
+    aux[0] = 0.5 + 2.0 * rng.random(full)
+    aux[1] = 0.5 + 1.5 * rng.random(full)
+    return q, aux
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_step3ds(coracle, seed):
+    L = _lib()
+    rng = np.random.default_rng(11000 + seed)
+    n = _shape3(rng)
+    q, aux = _state3(rng, n)
+    order = int(rng.integers(1, 3))
+    method = np.array([1, order, -1, 0, 0, 0, 2], dtype=np.int32)
+    mth = rng.integers(0, 6, size=2).astype(np.int32)
+    d = (0.1, 0.07, 0.13)
+    dt = 0.02
+    for idir in (1, 2, 3):
+        want = q.copy("F")
+        _, cfl_o = coracle.step3ds(O.RP_VC_ACOUSTICS_3D, max(n), 2, n[0], n[1], n[2], q.copy("F"), want, aux,
+                                   d[0], d[1], d[2], dt, method, mth, idir)
+        got = np.zeros_like(q)
+        cfl = C.c_double()
+        L.check(L.lib().pcl_step3ds(O.RP_VC_ACOUSTICS_3D, None, 4, 2, 2, 2, n[0], n[1], n[2], L.d(q), L.d(got), L.d(aux),
+                                    d[0], d[1], d[2], dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp), idir))
+        assert np.array_equal(got, want), "seed %d n %s idir %d" % (seed, n, idir)
+        assert cfl.value == cfl_o
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_step3_unsplit(coracle, seed):
+    L = _lib()
+    rng = np.random.default_rng(12000 + seed)
+    n = _shape3(rng)
+    q0, aux = _state3(rng, n)
+    trans = int(rng.choice([0, 10, 11, 20, 21, 22]))
+    order = 2 if trans >= 20 else int(rng.integers(1, 3))
+    method = np.array([1, order, trans, 0, 0, 0, 2], dtype=np.int32)
+    mth = rng.integers(0, 6, size=2).astype(np.int32)
+    d = (1.0 / n[0], 0.9 / n[1], 1.1 / n[2])
+    dt = 0.25 * min(d) / 2.0
+    ref = q0.copy("F")
+    _, cfl_ref = coracle.step3(O.RP_VC_ACOUSTICS_3D, max(n), 2, n[0], n[1], n[2], q0.copy("F"), ref, aux, d[0], d[1], d[2],
+                               dt, method, mth)
+    out = q0.copy("F")
+    cfl = C.c_double()
+    L.check(L.lib().pcl_step3(O.RP_VC_ACOUSTICS_3D, L.d(np.zeros(8)), 4, 2, 2, 2, n[0], n[1], n[2], L.d(q0), L.d(out), L.d(aux),
+                              d[0], d[1], d[2], dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
+    inner = (slice(None),) + (slice(2, -2),) * 3
+    assert np.array_equal(out[inner], ref[inner]), "seed %d n %s trans %d: max diff %g" % (
+        seed, n, trans, np.abs(out[inner] - ref[inner]).max())
+    assert cfl.value == cfl_ref
