@@ -262,7 +262,8 @@ template <class RP, int IXY, int K> int launch_sharp_k(const SweepLaunch &l, std
     } else a.sub = 0;
     const int n_across = IXY == 1 ? a.J : a.I + (LINE - a.mbc);
     const int m_along = IXY == 1 ? a.mx : a.my;
-    const int ntiles_across = (n_across + T_ACROSS_S - 1) / T_ACROSS_S;
+    constexpr int TA = sharp_tile_across<RP, IXY>();
+    const int ntiles_across = (n_across + TA - 1) / TA;
     const int ntiles_along = (m_along + SS - 1) / SS;
     const dim3 grid((unsigned)ntiles_across * (unsigned)ntiles_along);
     const bool capa = a.mcapa > 0;

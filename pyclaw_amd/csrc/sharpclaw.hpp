@@ -21,6 +21,9 @@ namespace pcl {
 namespace PCL_NS {
 
 constexpr int T_ACROSS_S = 16;
+// strips per tile: 16 (a 128-byte row segment per tile row) except in the y pass of solvers that stage many aux planes
+// through the tile (the sphere solver: 4 + 1 + 9 planes): 8 columns = 57 KB instead of 114 KB, two workgroups per CU
+template <class RP, int IXY> constexpr int sharp_tile_across() { return (IXY == 2 && RP::NAUX >= 6) ? 8 : T_ACROSS_S; }
 // halo of a strip = mbc = (weno_order+1)/2 (sharpclaw.py:479): 3 for WENO5 / tvd2, up to 9 for WENO17
 constexpr int sstrip(int halo) { return WAVE - 2 * halo; }   // cells updated per strip: 58 ... 46
 
@@ -194,8 +197,8 @@ __device__ __forceinline__ void tvd2_cell(double qm1, double q0, double qp1, int
 // y pass: rows of 16 doubles with the column XOR-swizzled by (al >> 1): a wavefront reading one column (lanes =
 // rows) touches 32 distinct 8-byte banks per half-wave, a thread group reading a row touches 16 consecutive ones
 // -- conflict-free both ways without the 17th padding column, which keeps the tile at 40 KB (4 per CU).
-template <int IXY> __device__ __forceinline__ int stile_at(int m, int al, int ac) {
-    return IXY == 1 ? (m * T_ACROSS_S + ac) * WAVE + al : (m * WAVE + al) * T_ACROSS_S + (ac ^ ((al >> 1) & 15));
+template <int IXY, int TA = T_ACROSS_S> __device__ __forceinline__ int stile_at(int m, int al, int ac) {
+    return IXY == 1 ? (m * TA + ac) * WAVE + al : (m * WAVE + al) * TA + (ac ^ ((al >> 1) & (TA - 1)));
 }
 
 #ifndef PCL_SHARP_OCC
@@ -212,7 +215,9 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
     // 3-4 workgroups per CU instead of 1.  y pass: aux goes through the tile like q (the transposition).
     constexpr int NAUX_LDS = IXY == 1 ? 0 : NAUX;
     constexpr int NP = PAUX + NAUX_LDS;
-    constexpr int PLANE = T_ACROSS_S * WAVE;
+    constexpr int TA = sharp_tile_across<RP, IXY>();     // strips (columns / rows across the sweep) per tile
+    constexpr int NLD = TA * WAVE / 256;                   // cells each thread loads / stores
+    constexpr int PLANE = TA * WAVE;
     using Cell = typename RP::Cell;
     __shared__ double tile[NP * PLANE];
 
@@ -226,26 +231,26 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
         const bool inside = tb >= a.box[0] && tb < a.box[1] && ta >= a.box[2] && ta < a.box[3];
         if ((a.sub == 1) != inside) return;             // workgroup-uniform, before any barrier
     }
-    const int b0 = IXY == 1 ? tb * T_ACROSS_S : tb * T_ACROSS_S - (LINE - a.mbc);
+    const int b0 = IXY == 1 ? tb * TA : tb * TA - (LINE - a.mbc);
     const int a0 = a.mbc - SHALO + ta * SSTRIP;
 
     // cooperative load (memory-contiguous index fastest)
-    const int l_al = IXY == 1 ? threadIdx.x % WAVE : threadIdx.x / T_ACROSS_S;
-    const int l_ac = IXY == 1 ? threadIdx.x / WAVE : threadIdx.x % T_ACROSS_S;
-    constexpr int STEP_AL = IXY == 1 ? 0 : 256 / T_ACROSS_S;
+    const int l_al = IXY == 1 ? threadIdx.x % WAVE : threadIdx.x / TA;
+    const int l_ac = IXY == 1 ? threadIdx.x / WAVE : threadIdx.x % TA;
+    constexpr int STEP_AL = IXY == 1 ? 0 : 256 / TA;
     constexpr int STEP_AC = IXY == 1 ? 256 / WAVE : 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NLD; k++) {
         const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
         int ga = a0 + al, gb = b0 + ac;
         ga = ga < n_along ? ga : n_along - 1;
         gb = gb < 0 ? 0 : (gb < n_across ? gb : n_across - 1);
         const long g = IXY == 1 ? (long)gb * a.pitch + ga : (long)ga * a.pitch + gb;
 #pragma unroll
-        for (int m = 0; m < MEQN; m++) tile[stile_at<IXY>(m, al, ac)] = a.qin[m * a.plane + g];
-        if constexpr (CAPA) tile[stile_at<IXY>(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
+        for (int m = 0; m < MEQN; m++) tile[stile_at<IXY, TA>(m, al, ac)] = a.qin[m * a.plane + g];
+        if constexpr (CAPA) tile[stile_at<IXY, TA>(MEQN, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
 #pragma unroll
-        for (int m = 0; m < NAUX_LDS; m++) tile[stile_at<IXY>(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + g];
+        for (int m = 0; m < NAUX_LDS; m++) tile[stile_at<IXY, TA>(PAUX + m, al, ac)] = a.aux[aux_idx<RP, IXY>(m) * a.plane + g];
     }
     __syncthreads();
 
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
     const int lm2 = lane >= 2 ? lane - 2 : 0, lm1 = lane >= 1 ? lane - 1 : 0;
     const int lp1 = lane <= WAVE - 2 ? lane + 1 : WAVE - 1, lp2 = lane <= WAVE - 3 ? lane + 2 : WAVE - 1;
     double cflmax = 0.0;
-    for (int ac = wv; ac < T_ACROSS_S; ac += 256 / WAVE) {
+    for (int ac = wv; ac < TA; ac += 256 / WAVE) {
         const int gb = b0 + ac;
         if (gb >= n_across) break;  // wave-uniform
         // flux2.f90:38,70: slices 0..m+1 only (one ghost layer)
@@ -267,16 +272,16 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
         double ql[MEQN], qr[MEQN];
 #pragma unroll
         for (int m = 0; m < MEQN; m++) {
-            const double qm2 = tile[stile_at<IXY>(m, lm2, ac)], qm1 = tile[stile_at<IXY>(m, lm1, ac)];
-            const double q0 = tile[stile_at<IXY>(m, lane, ac)];
-            const double qp1 = tile[stile_at<IXY>(m, lp1, ac)], qp2 = tile[stile_at<IXY>(m, lp2, ac)];
+            const double qm2 = tile[stile_at<IXY, TA>(m, lm2, ac)], qm1 = tile[stile_at<IXY, TA>(m, lm1, ac)];
+            const double q0 = tile[stile_at<IXY, TA>(m, lane, ac)];
+            const double qp1 = tile[stile_at<IXY, TA>(m, lp1, ac)], qp2 = tile[stile_at<IXY, TA>(m, lp2, ac)];
             if constexpr (K > 3) {
                 double qs[2 * K - 1];
 #pragma unroll
                 for (int j = 0; j < 2 * K - 1; j++) {
                     int l = lane - (K - 1) + j;
                     l = l < 0 ? 0 : (l > WAVE - 1 ? WAVE - 1 : l);
-                    qs[j] = tile[stile_at<IXY>(m, l, ac)];
+                    qs[j] = tile[stile_at<IXY, TA>(m, l, ac)];
                 }
                 weno_pyweno_k<K>(qs, ql[m], qr[m]);
             } else if (LIM == 1) tvd2_cell(qm1, q0, qp1, a.mthlim[m < MAX_WAVES_K ? m : MAX_WAVES_K - 1], ql[m], qr[m]);
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
             else weno5_legacy(qm2, qm1, q0, qp1, qp2, ql[m], qr[m]);
         }
         double dtdx_c = a.dtd;
-        if constexpr (CAPA) dtdx_c = a.dt / (a.dx * tile[stile_at<IXY>(MEQN, lane, ac)]);  // flux1.f90:60
+        if constexpr (CAPA) dtdx_c = a.dt / (a.dx * tile[stile_at<IXY, TA>(MEQN, lane, ac)]);  // flux1.f90:60
         const double dtdx_l = CAPA ? from_left(dtdx_c) : dtdx_c;
 
         // both edge states carry the cell's own aux values (flux1.f90:125 passes aux,aux)
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
             for (int m = 0; m < NAUX; m++) auxv[m] = a.aux[aux_idx<RP, 1>(m) * a.plane + g];
         } else {
 #pragma unroll
-            for (int m = 0; m < NAUX; m++) auxv[m] = tile[stile_at<IXY>(PAUX + m, lane, ac)];
+            for (int m = 0; m < NAUX; m++) auxv[m] = tile[stile_at<IXY, TA>(PAUX + m, lane, ac)];
         }
         Cell cl, cr;
         if constexpr (NAUX > 0) {
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
         }
         if (owned) {
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) tile[stile_at<IXY>(m, lane, ac)] = dq1[m];
+            for (int m = 0; m < MEQN; m++) tile[stile_at<IXY, TA>(m, lane, ac)] = dq1[m];
         }
     }
     __syncthreads();
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
     // (rp.hpp Recip; dq is a normal-range quantity or exactly zero) instead of 20 IEEE divisions per thread
     const Recip by_ca(a.rk_op == 1 ? a.rk_ca : 1.0);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NLD; k++) {
         const int al = l_al + k * STEP_AL, ac = l_ac + k * STEP_AC;
         const int ga = a0 + al, gb = b0 + ac;
         const bool inner_al = (ga >= a.mbc) && (ga < a.mbc + m_along) && al >= SHALO && al < WAVE - SHALO;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
                 const long at = m * a.plane + g;
-                const double v = tile[stile_at<IXY>(m, al, ac)];
+                const double v = tile[stile_at<IXY, TA>(m, al, ac)];
                 const double dq = IXY == 1 ? v : a.qout[at] + v;  // dq = (0 + dq1d_x) + dq1d_y
                 // last pass of a stage: the RK combination of sharpclaw.py:168-206 (same expressions as rk_kernel).
                 // Branch-free on purpose: with a scalar branch per op the ROCm 7.2 backend left the store base
