@@ -12,9 +12,11 @@
 // 2-cell halo on each side, so a wavefront updates lanes 2..61 (60 cells).
 //
 // Device layout of q: structure-of-arrays planes, q[m][j][i], i fastest, row pitch a
-// multiple of 16 doubles: the x pass reads rows straight from HBM fully coalesced; the
-// y pass stages a 64-row x 16-column tile through LDS (coalesced 128-B row segments in,
-// column strips out) so both passes run the same lane-per-cell core.
+// multiple of 16 doubles, first interior cell of a row on a 128-byte line.  Both passes stage
+// tiles through LDS (x: 4 rows x 244 cells; y: 64 rows x 16 columns, coalesced 128-byte row
+// segments in, column strips out) and run the same lane-per-cell core (lane_core).
+// Contents: lane_core | sweep_kernel (step2ds / step1) | unsplit_x/y_kernel (step2, step2qcor) |
+// sweep3_kernel (step3ds); the unsplit 3-D step is classic3.hpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     cfl_publish(a.cfl, cfl_value<CAPA>(cflmax, a.dtd));
 }
 
-// ---- unsplit algorithm without scratch planes (no capacity function) ---------------------------------
+// ---- unsplit algorithm (step2.f / step2qcor.f), with and without a capacity function -------------------
 // A workgroup of U_WAVES wavefronts takes U_WAVES consecutive slices (x phase: rows of one 64-cell
 // strip; y phase: columns of one 64-row strip).  Every wavefront computes its slice's pieces with the
 // TRANS core, publishes dt/d*gadd(.,1,.) and dt/d*gadd(.,2,.) in LDS, and after one barrier each of

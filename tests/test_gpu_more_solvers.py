@@ -497,7 +497,7 @@ def test_vc_advection2d_all_kernel_families(coracle, shape):
 @pytest.mark.parametrize("trans", [0, 2])
 def test_vc_solvers_unsplit_with_capacity_function(coracle, rp_name, trans):
     """the annulus app's configuration (apps/advection/2d/annulus: unsplit, order_trans=2, mcapa=2 -> third aux
-    component): per-slice pieces through the scratch planes, every increment divided by capa of its target cell"""
+    component): the LDS-exchange unsplit kernels with CAPA, every increment divided by capa of its target cell"""
     from pyclaw_amd import _lib as L
     mx, my = 44, 57
     rng = np.random.default_rng(trans)
