@@ -291,10 +291,14 @@ int pcl_sync(pcl_solver *s);
 /* Timing hooks for bench.py: HIP events recorded on the solver's compute stream. */
 int pcl_timer_start(pcl_solver *s);
 int pcl_timer_stop(pcl_solver *s, float *ms);
-/* Cumulative device time (ms) and launch count of the sweep kernels since the last
- * reset, from HIP events around every sweep launch (enable before use). */
+/* Cumulative device time (ms) and launch count of the sweep kernels since the last reset, from HIP events around
+ * the sweep launches (enable before use).  enable = 0: off; 1: every step; N > 1: every N-th step (the event
+ * records sit between the kernels and cost a few microseconds of dispatch gap each; sampling keeps the average
+ * launch duration and removes most of that). */
 int pcl_kernel_timing(pcl_solver *s, int enable);
 int pcl_kernel_timing_read(pcl_solver *s, double *ms_total, long *launches);
+/* hyperbolic steps (classic) / right-hand sides (SharpClaw) attempted since pcl_create, rejected ones included */
+int pcl_step_count(pcl_solver *s, long *steps);
 
 /* ---- multi-GPU: one block per process, RCCL over xGMI -------------------------------- */
 /* Replaces PETSc DMDA globalToLocal (src/petclaw/state.py:254-269) and Vec.max

@@ -55,7 +55,8 @@ struct pcl_solver {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_cfl = nullptr;
     double **undo_slot = nullptr;  // buffer that holds the pre-step state
-    bool timing = false;
+    int timing = 0;       // 0 off, N >= 1: HIP events around the sweep launches of every N-th step (pcl_kernel_timing)
+    long step_no = 0;     // hyperbolic steps / stages completed (read_cfl)
     int vbc_on = 0;       // next x pass evaluates these BCs while loading (pcl_bc_step)
     int vbc[4] = {-1, -1, -1, -1};
     double vconst[4][8] = {};
@@ -72,6 +73,7 @@ struct pcl_solver {
 };
 
 static inline double *&cur(pcl_solver *s) { return s->sel == 0 ? s->q : s->sreg[s->sel]; }
+static inline bool timing_on(const pcl_solver *s) { return s->timing > 0 && s->step_no % s->timing == 0; }
 
 namespace pcl { namespace exact { void launch_shift_test(const double *in, double *l, double *r); } }
 
@@ -313,7 +315,7 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
     a.sub = sub;
     if (sub) for (int k = 0; k < 4; k++) a.box[k] = box[k];
     pcl_solver::Timed t{};
-    const bool timed = s->timing && !on;  // a launch on the halo stream runs beside the interior: not timed
+    const bool timed = timing_on(s) && !on;  // a launch on the halo stream runs beside the interior: not timed
     if (timed) {
         t.a = get_event(s);
         t.b = get_event(s);
@@ -356,7 +358,7 @@ int do_sweep3(pcl_solver *s, const double *qin, double *qout, int dir, double dt
     a.lo_b = mbc - 1; a.hi_b = mbc + s->cfg.n[bt];
     a.vbc_on = 0;
     pcl_solver::Timed t{};
-    if (s->timing) {
+    if (timing_on(s)) {
         t.a = get_event(s);
         t.b = get_event(s);
         t.which = dir == 1 ? 0 : 1;
@@ -373,7 +375,7 @@ int do_sweep3(pcl_solver *s, const double *qin, double *qout, int dir, double dt
     std::string err;
     int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sweep3(l, err) : pcl::exact::launch_sweep3(l, err);
     if (rc) fail(rc, err);
-    if (s->timing) {
+    if (timing_on(s)) {
         hipEventRecord(t.b, s->stream);
         s->timed.push_back(t);
         if (s->timed.size() >= 2048) drain_timing(s);
@@ -415,9 +417,9 @@ int do_unsplit3(pcl_solver *s, double dt) {
         l.dir = dir; l.rp = s->cfg.rp; l.stream = s->stream;
         (void)mbc;
         pcl_solver::Timed t{};
-        if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = dir == 1 ? 0 : 1; t.count = true; hipEventRecord(t.a, s->stream); }
+        if (timing_on(s)) { t.a = get_event(s); t.b = get_event(s); t.which = dir == 1 ? 0 : 1; t.count = true; hipEventRecord(t.a, s->stream); }
         int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit3(l, err) : pcl::exact::launch_unsplit3(l, err);
-        if (s->timing) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
+        if (timing_on(s)) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
         if (rc) return fail(rc, err);
     }
     return PCL_OK;
@@ -488,10 +490,10 @@ static int unsplit_phase(pcl_solver *s, int ids, double dt, int sub, hipStream_t
     l.a.sub = sub;
     l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = stream;
     pcl_solver::Timed t{};
-    if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
+    if (timing_on(s)) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
     int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit(l, s->t1, err)
                                           : pcl::exact::launch_unsplit(l, s->t1, err);
-    if (s->timing) { hipEventRecord(t.b, stream); s->timed.push_back(t); }
+    if (timing_on(s)) { hipEventRecord(t.b, stream); s->timed.push_back(t); }
     if (rc) return fail(rc, err);
     return PCL_OK;
 }
@@ -521,6 +523,7 @@ __global__ void cfl_handover(unsigned long long *word, unsigned long long *host,
 // The step's Courant number: in a decomposed run the max over all blocks (petclaw/cfl.py:29-31),
 // reduced on the device before the single 8-byte read-back.
 int read_cfl(pcl_solver *s, double *cfl) {
+    s->step_no++;           // every launch of the step / stage is enqueued: the next one decides afresh whether it is timed
     if (s->halo.active) {
         std::string err;
         if (s->halo.allreduce_max_device(reinterpret_cast<double *>(s->cfl_dev), err)) return fail(PCL_ECOMM, err);
@@ -1175,9 +1178,9 @@ static int sharp_pass(pcl_solver *s, int ids, double dt, int rk_op, const double
     l.ndim = s->cfg.ndim; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave;
     l.lim_type = s->cfg.lim_type; l.stream = stream;
     pcl_solver::Timed t{};
-    if (s->timing) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
+    if (timing_on(s)) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
     int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sharp(l, err) : pcl::exact::launch_sharp(l, err);
-    if (s->timing) { hipEventRecord(t.b, stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
+    if (timing_on(s)) { hipEventRecord(t.b, stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
     if (rc) return fail(rc, err);
     return PCL_OK;
 }
@@ -1342,9 +1345,14 @@ int pcl_timer_stop(pcl_solver *s, float *ms) {
 int pcl_kernel_timing(pcl_solver *s, int enable) {
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (int rc = drain_timing(s)) return rc;
-    s->timing = enable != 0;
+    s->timing = enable < 0 ? 0 : enable;
     s->kt_ms[0] = s->kt_ms[1] = 0;
     s->kt_n[0] = s->kt_n[1] = 0;
+    return PCL_OK;
+}
+int pcl_step_count(pcl_solver *s, long *steps) {
+    if (!s || !steps) return fail(PCL_EINVAL, "null argument");
+    *steps = s->step_no;
     return PCL_OK;
 }
 int pcl_kernel_timing_read(pcl_solver *s, double *ms_total, long *launches) {
