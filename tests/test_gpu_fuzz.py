@@ -6,6 +6,7 @@ ones, so the jump-free shortcut and the absent-family skips switch on and off in
 the f2py-shaped C ABI against the C oracle, bit for bit, Courant number included.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -20,6 +21,8 @@ def _lib():
     return L
 
 
+# PCL_FUZZ_MULT=10 runs ten times as many seeds (a one-off wider sweep; the default set is what the suite pins)
+MULT = int(os.environ.get("PCL_FUZZ_MULT", "1"))
 EDGES = [1, 2, 3, 13, 14, 15, 16, 17, 28, 29, 57, 58, 59, 60, 61, 62, 63, 64, 65, 116, 119, 120, 121, 122, 179, 180,
          181, 239, 240, 241, 242, 243, 244, 245, 300, 479, 480, 481, 484]
 
@@ -56,7 +59,7 @@ def patchy_euler(rng, shape):
     return q
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * MULT))
 def test_fuzz_step2ds(coracle, seed):
     L = _lib()
     rng = np.random.default_rng(7000 + seed)
@@ -85,7 +88,7 @@ def test_fuzz_step2ds(coracle, seed):
         assert cfl.value == cfl_ref
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * MULT))
 def test_fuzz_step2_unsplit(coracle, seed):
     L = _lib()
     rng = np.random.default_rng(8000 + seed)
@@ -113,7 +116,7 @@ def test_fuzz_step2_unsplit(coracle, seed):
     assert cfl.value == cfl_ref
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * MULT))
 def test_fuzz_sharp_flux2(coracle, seed):
     L = _lib()
     rng = np.random.default_rng(9000 + seed)
@@ -174,7 +177,7 @@ def _state3(rng, n, mbc=2):
     return q, aux
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * MULT))
 def test_fuzz_step3ds(coracle, seed):
     L = _lib()
     rng = np.random.default_rng(11000 + seed)
@@ -197,7 +200,7 @@ def test_fuzz_step3ds(coracle, seed):
         assert cfl.value == cfl_o
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * MULT))
 def test_fuzz_step3_unsplit(coracle, seed):
     L = _lib()
     rng = np.random.default_rng(12000 + seed)
