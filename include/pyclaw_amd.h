@@ -309,6 +309,17 @@ int pcl_step_count(pcl_solver *s, long *steps);
 int pcl_comm_unique_id(char uid[128]);
 int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128],
                   const int neighbors[8]);
+/* The same decomposed device path with a host-staged wire instead of RCCL (diagnostics, and multi-process tests on
+ * ONE device: RCCL refuses two ranks per GPU).  Packed strips go to pinned host memory, `xfn` carries them between
+ * the processes, the received strips go back up; the CFL maximum goes through `rfn`.  send/recv: all 8 directions'
+ * strips back to back, direction d at doubles [off[d]*nm, (off[d]+cnt[d])*nm); what is SENT towards d arrives in the
+ * receiver's region opposite(d).  Both callbacks return 0 on success and are called by every rank of the group at
+ * the same points (collectives).  No reference counterpart. */
+typedef int (*pcl_host_exchange_fn)(void *user, const double *send, double *recv, const long *off, const long *cnt,
+                                    const int *nbr, int nm);
+typedef int (*pcl_host_reduce_fn)(void *user, double *value);     /* in-place max over the ranks */
+int pcl_comm_init_host(pcl_solver *s, int nranks, int rank, const int neighbors[8], pcl_host_exchange_fn xfn,
+                       pcl_host_reduce_fn rfn, void *user);
 /* Host-only argument check of pcl_comm_init (no GPU, no RCCL): rank inside 0..nranks-1, every neighbour a
  * rank of the communicator or -1, a self-neighbour only on both faces of a dimension.  pcl_comm_init runs it
  * first, so misuse fails with a message instead of RCCL's "invalid usage". */

@@ -138,6 +138,45 @@ public:
         return 0;
     }
 
+    // ---- host-staged transport (diagnostics / multi-process tests on ONE device) ---------------------------
+    // Same plan, same pack / unpack kernels, same call sites and stream choreography; only the wire differs: the
+    // packed strips go to pinned host memory, a callback of the embedding program carries them between the
+    // processes (pyclaw_amd.parallel: its TCP group), and the received strips go back up.  RCCL refuses two ranks on
+    // one device, so this is how 2-6 ranks sharing one GPU exercise the whole decomposed device path.  Blocking.
+    typedef int (*ExchangeFn)(void *user, const double *send, double *recv, const long *off, const long *cnt,
+                              const int *nbr, int nm);
+    typedef int (*ReduceFn)(void *user, double *value);
+    int init_host(int nranks, int rank, const int nbr[8], int I, int J, int g, int nmax, hipStream_t stream,
+                  ExchangeFn xfn, ReduceFn rfn, void *user, std::string &err, int elem = 1, long pi = 1, long pj = 0) {
+        destroy();
+        (void)rank;
+        stream_ = stream;
+        plan_.I = I; plan_.J = J; plan_.g = g;
+        plan_.elem = elem; plan_.pi = pi; plan_.pj = pj;
+        long off = 0;
+        for (int d = 0; d < 8; d++) {
+            if (nbr[d] >= nranks) { err = "neighbour rank out of range"; return -1; }
+            plan_.nbr[d] = nbr[d];
+            const HaloRegion r = halo_region(d, true, I, J, g);
+            plan_.cnt[d] = (long)r.ni * r.nj * elem;
+            plan_.off[d] = off;
+            off += plan_.cnt[d];
+        }
+        cells_ = off;
+        const size_t bytes = (size_t)cells_ * nmax * sizeof(double);
+        if (hipMalloc((void **)&send_, bytes) != hipSuccess || hipMalloc((void **)&recv_, bytes) != hipSuccess ||
+            hipMalloc((void **)&red_, 64) != hipSuccess ||
+            hipHostMalloc((void **)&red_host_, 64, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&hsend_, bytes, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&hrecv_, bytes, hipHostMallocDefault) != hipSuccess) {
+            err = "halo buffer allocation failed";
+            return -1;
+        }
+        xfn_ = xfn; rfn_ = rfn; user_ = user;
+        active = true;
+        return 0;
+    }
+
     bool has(int d) const { return active && plan_.nbr[d] >= 0; }
 
     // exchange the ghost frame of an nm-component SoA array
@@ -148,6 +187,16 @@ public:
         hipStream_t stream_ = on ? on : this->stream_;
         dim3 grid(64, 8);
         hipLaunchKernelGGL(halo_pack, grid, dim3(256), 0, stream_, q, send_, plan_, nm, pitch, plane, false);
+        if (xfn_) {
+            const size_t bytes = (size_t)cells_ * nm * sizeof(double);
+            if (hipMemcpyAsync(hsend_, send_, bytes, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+                hipStreamSynchronize(stream_) != hipSuccess) { err = "halo D2H failed"; return -1; }
+            if (xfn_(user_, hsend_, hrecv_, plan_.off, plan_.cnt, plan_.nbr, nm)) { err = "host halo transport failed"; return -1; }
+            if (hipMemcpyAsync(recv_, hrecv_, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) { err = "halo H2D failed"; return -1; }
+            hipLaunchKernelGGL(halo_pack, grid, dim3(256), 0, stream_, q, recv_, plan_, nm, pitch, plane, true);
+            if (hipGetLastError() != hipSuccess) { err = "halo pack/unpack launch failed"; return -1; }
+            return 0;
+        }
         ncclResult_t r = a.ncclGroupStart();
         for (int d = 0; d < 8 && r == ncclSuccess; d++) {
             // what I send towards d fills the receiver's ghost strip on its opposite(d) side
@@ -171,6 +220,15 @@ public:
     // enqueued on the solver stream: no extra host round trip
     int allreduce_max_device(double *dev, std::string &err) {
         if (!active) return 0;
+        if (rfn_) {
+            if (hipMemcpyAsync(red_host_, dev, sizeof(double), hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+                hipStreamSynchronize(stream_) != hipSuccess) { err = "allreduce D2H failed"; return -1; }
+            if (rfn_(user_, red_host_)) { err = "host allreduce failed"; return -1; }
+            if (hipMemcpyAsync(dev, red_host_, sizeof(double), hipMemcpyHostToDevice, stream_) != hipSuccess) {
+                err = "allreduce H2D failed"; return -1;
+            }
+            return 0;
+        }
         ncclResult_t r = api().ncclAllReduce(dev, dev, 1, ncclDouble, ncclMax, comm_, stream_);
         if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + api().ncclGetErrorString(r); return -1; }
         return 0;
@@ -178,6 +236,10 @@ public:
 
     int allreduce_max(double *v, std::string &err) {
         if (!active) { err = "allreduce before pcl_comm_init"; return -1; }
+        if (rfn_) {
+            if (rfn_(user_, v)) { err = "host allreduce failed"; return -1; }
+            return 0;
+        }
         Api &a = api();
         *red_host_ = *v;
         if (hipMemcpyAsync(red_, red_host_, sizeof(double), hipMemcpyHostToDevice, stream_) != hipSuccess) {
@@ -199,7 +261,10 @@ public:
         if (recv_) hipFree(recv_);
         if (red_) hipFree(red_);
         if (red_host_) hipHostFree(red_host_);
-        send_ = recv_ = red_ = nullptr; red_host_ = nullptr;
+        if (hsend_) hipHostFree(hsend_);
+        if (hrecv_) hipHostFree(hrecv_);
+        send_ = recv_ = red_ = nullptr; red_host_ = hsend_ = hrecv_ = nullptr;
+        xfn_ = nullptr; rfn_ = nullptr; user_ = nullptr;
         active = false;
     }
 
@@ -223,6 +288,10 @@ private:
     HaloPlan plan_{};
     long cells_ = 0;
     double *send_ = nullptr, *recv_ = nullptr, *red_ = nullptr, *red_host_ = nullptr;
+    double *hsend_ = nullptr, *hrecv_ = nullptr;     // host-staged transport
+    ExchangeFn xfn_ = nullptr;
+    ReduceFn rfn_ = nullptr;
+    void *user_ = nullptr;
 };
 
 }  // namespace pcl

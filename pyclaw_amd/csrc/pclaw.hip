@@ -462,7 +462,7 @@ __global__ void frame_kernel(double *q, double *dst, int nm, int I, int J, int m
             v = ci ? f.c[sdi][m < 8 ? m : 7] : v;
             if (m == 2) v = nj ? -v : v;
             v = cj ? f.c[2 + sdj][m < 8 ? m : 7] : v;
-            if (gs != g) q[m * plane + g] = v;
+            if (gs != g || ci || cj) q[m * plane + g] = v;      // (a constant-state cell maps to itself)
             if (dst) dst[m * plane + g] = v;
         }
     }
@@ -1619,6 +1619,30 @@ int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], cons
                                        s->pitch, s->pitch * s->J)
                         : s->halo.init(nranks, rank, uid, neighbors, s->I, s->J, s->cfg.mbc, nmax, s->stream, err, 1, 1,
                                        s->pitch);
+    if (rc3) return fail(PCL_ECOMM, err);
+    if (!s->hstream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_h0, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
+    }
+    const char *e = getenv("PCL_HALO_OVERLAP");
+    s->overlap = e ? atoi(e) : 1;
+    return PCL_OK;
+}
+
+int pcl_comm_init_host(pcl_solver *s, int nranks, int rank, const int neighbors[8], pcl_host_exchange_fn xfn,
+                       pcl_host_reduce_fn rfn, void *user) {
+    if (!s || !neighbors || !xfn || !rfn) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.ndim < 2) return fail(PCL_EINVAL, "halo exchange is implemented for 2-D blocks and 3-D blocks decomposed over (y, z)");
+    if (int rc = pcl_comm_check(nranks, rank, neighbors)) return rc;
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    std::string err;
+    const int nmax = s->cfg.meqn > s->cfg.maux ? s->cfg.meqn : s->cfg.maux;
+    const int rc3 = s->cfg.ndim == 3
+                        ? s->halo.init_host(nranks, rank, neighbors, s->J, s->K, s->cfg.mbc, nmax, s->stream, xfn, rfn, user,
+                                            err, s->I, s->pitch, s->pitch * s->J)
+                        : s->halo.init_host(nranks, rank, neighbors, s->I, s->J, s->cfg.mbc, nmax, s->stream, xfn, rfn, user,
+                                            err, 1, 1, s->pitch);
     if (rc3) return fail(PCL_ECOMM, err);
     if (!s->hstream) {
         HIP_TRY(hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking));

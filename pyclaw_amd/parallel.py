@@ -231,6 +231,59 @@ def allreduce_max_host(value):
     return max(float(v) for v in g.allgather(float(value)))
 
 
+_OPP = [1, 0, 3, 2, 7, 6, 5, 4]      # W,E,S,N,SW,SE,NW,NE -> opposite (csrc/halo.hpp)
+
+
+def host_transport():
+    """ctypes callbacks for pcl_comm_init_host (PCL_HALO_TRANSPORT=host): the packed halo strips and the CFL maximum
+    travel over this module's TCP group instead of RCCL.  Diagnostics and multi-process tests on ONE device only
+    (every exchange is an allgather of all strips through rank 0).  Returns (exchange_cb, reduce_cb): keep them alive."""
+    import base64
+    import ctypes as C
+    lp = C.POINTER(C.c_long)
+    ip = C.POINTER(C.c_int)
+    dp = C.POINTER(C.c_double)
+    XFN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, lp, lp, ip, C.c_int)
+    RFN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp)
+
+    def exchange(user, send, recv, off, cnt, nbr, nm):
+        try:
+            g = _state["group"]
+            me = rank()
+            out = {}
+            for d in range(8):
+                if nbr[d] >= 0:
+                    a, n = off[d] * nm, cnt[d] * nm
+                    raw = C.string_at(C.addressof(send.contents) + 8 * a, 8 * n)
+                    out["%d" % d] = base64.b64encode(raw).decode("ascii")
+            allm = g.allgather({"from": me, "msgs": out})
+            by_rank = dict((m["from"], m["msgs"]) for m in allm)
+            for o in range(8):
+                if nbr[o] < 0:
+                    continue
+                # the strip for my side o is what the block on that side sent towards opposite(o), i.e. towards me
+                raw = base64.b64decode(by_rank[int(nbr[o])]["%d" % _OPP[o]])
+                if len(raw) != 8 * cnt[o] * nm:
+                    return 2
+                C.memmove(C.addressof(recv.contents) + 8 * off[o] * nm, raw, len(raw))
+            return 0
+        except Exception:            # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def reduce_max(user, value):
+        try:
+            value[0] = allreduce_max_host(value[0])
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return XFN(exchange), RFN(reduce_max)
+
+
 def allreduce_sum_host(values):
     """Host-side sum all-reduce of a short list (output functionals at output times); summed in rank order."""
     g = _state["group"]

@@ -352,13 +352,23 @@ class Solver(object):
             return
         L = _lib.lib()
         import ctypes as C
+        import os
+        periodic = [self.bc_lower[k] == BC.periodic for k in range(state.grid.ndim)]
+        nbr = np.array(dec.neighbors(periodic), dtype=np.int32)
+        if os.environ.get("PCL_HALO_TRANSPORT", "rccl") == "host":
+            # host-staged wire (diagnostics; several ranks on ONE device): same device path, TCP instead of RCCL
+            self._host_transport = parallel.host_transport()
+            xfn, rfn = self._host_transport
+            _lib.check(L.pcl_comm_init_host(self._h, parallel.world_size(), parallel.rank(), _lib.i(nbr),
+                                            C.cast(xfn, C.c_void_p), C.cast(rfn, C.c_void_p), None))
+            self._halo_active = True
+            self.cfl._reduce = None
+            return
         uid = C.create_string_buffer(128)
         if parallel.rank() == 0:
             _lib.check(L.pcl_comm_unique_id(uid))
         raw = parallel.broadcast_bytes(uid.raw if parallel.rank() == 0 else None, src=0)
         uid = C.create_string_buffer(raw, 128)
-        periodic = [self.bc_lower[k] == BC.periodic for k in range(state.grid.ndim)]
-        nbr = np.array(dec.neighbors(periodic), dtype=np.int32)
         _lib.check(L.pcl_comm_init(self._h, parallel.world_size(), parallel.rank(), uid, _lib.i(nbr)))
         self._halo_active = True
         # the CFL all-reduce (petclaw/cfl.py:29-31) happens inside pcl_step_hyperbolic /

@@ -1,0 +1,93 @@
+"""
+Worker for tests/test_gpu_multiproc.py: one of N processes that SHARE ONE GPU (PCL_FORCE_DEVICE=0) and run the
+product's decomposed device path end to end -- decomposition, device pack / unpack kernels, neighbour tables, the
+interior / rim stream choreography, boundary conditions on edge blocks only, the CFL maximum over the blocks -- with
+the host-staged wire (PCL_HALO_TRANSPORT=host: the strips travel over pyclaw_amd.parallel's TCP group instead of
+RCCL, which refuses two ranks on one device).  Rank 0 gathers the blocks and compares the assembled field with the
+SERIAL oracle replay: bit for bit.
+
+  python tests/mp_gpu_worker.py <case>       with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment
+"""
+import base64
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import pyclaw_amd as pyclaw                  # noqa: E402
+from pyclaw_amd import parallel             # noqa: E402
+from apps import problems                   # noqa: E402
+
+
+def run_case(case):
+    if case == "shockbubble_ds":
+        claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=True)
+    elif case == "shockbubble_unsplit":
+        claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=True, dim_split=False)
+    elif case == "acoustics_ds":
+        claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.06, nout=2)
+    elif case == "acoustics_unsplit":
+        claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.06, nout=2, dim_split=0)
+    elif case == "acoustics_sharp":
+        claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.03, nout=1, solver_type='sharpclaw')
+    else:
+        raise SystemExit("unknown case " + case)
+    return claw
+
+
+def oracle_case(case):
+    from oracle import driver as D
+    from oracle import oracle as O
+    co = O.COracle()
+    if case.startswith("shockbubble"):
+        p = D.shockbubble_problem(mx=160, my=40, dim_split=case.endswith("_ds"))
+        D.run(p, co, 0.03, 1)
+    elif case == "acoustics_sharp":
+        p = D.acoustics2d_problem(mx=90, my=80, solver_type='sharpclaw')
+        D.run(p, co, 0.03, 1)
+    else:
+        # order_trans: the solver default (trans_inc, clawpack.py:460), which apps/problems.acoustics2D keeps
+        p = D.acoustics2d_problem(mx=90, my=80, dim_split=case.endswith("_ds"), order_trans=1)
+        D.run(p, co, 0.06, 2)
+    return p.q, p
+
+
+def main():
+    case = sys.argv[1]
+    parallel.init()
+    rank, size = parallel.rank(), parallel.world_size()
+    claw = run_case(case)
+    st = claw.frames[claw.nout].state
+    rng = [(d.nstart, d.nend) for d in st.grid.dimensions]
+    g = parallel._state["group"]
+    blocks = g.allgather({"rank": rank, "rng": rng, "shape": list(st.q.shape),
+                          "q": base64.b64encode(np.ascontiguousarray(st.q).tobytes()).decode("ascii"),
+                          "steps": int(claw.solver.status["numsteps"])})
+    ok = 0
+    if rank == 0:
+        ref, p = oracle_case(case)
+        full = np.full(ref.shape, np.nan)
+        for b in blocks:
+            q = np.frombuffer(base64.b64decode(b["q"]), dtype=np.float64).reshape(b["shape"])
+            (i0, i1), (j0, j1) = b["rng"]
+            full[:, i0:i1, j0:j1] = q
+        nb = len(set(tuple(map(tuple, b["rng"])) for b in blocks))
+        same = np.array_equal(full, ref)
+        if not same:
+            bad = np.argwhere(~((full == ref) | (np.isnan(full) & np.isnan(ref))))
+            print("mismatches: %d cells; NaN in result %d, in reference %d; first at %s; i range %s j range %s"
+                  % (len(bad), np.isnan(full).sum(), np.isnan(ref).sum(), bad[:6].tolist(),
+                     (bad[:, 1].min(), bad[:, 1].max()), (bad[:, 2].min(), bad[:, 2].max())))
+        print("case %s: %d ranks, %d distinct blocks, steps %s, max |diff| %g, bit-identical: %s"
+              % (case, size, nb, sorted(set(b["steps"] for b in blocks)), np.nanmax(np.abs(full - ref)), same))
+        ok = 0 if (same and nb == size) else 3
+    parallel.barrier()
+    parallel.shutdown()
+    sys.exit(ok)
+
+
+if __name__ == "__main__":
+    main()

@@ -461,3 +461,50 @@ def test_overlapped_sharpclaw_stage_equals_periodic(mx, my, overlap, fused, monk
     assert res[0][1] == res[1][1] and 0 < res[0][1][0] < 1
     assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
     assert not np.array_equal(res[0][0], q0)
+
+
+def test_unsplit_frame_constant_state_bc():
+    """pcl_bc_step on an unsplit solver: the one-launch ghost frame with a CONSTANT-STATE side (the shock-bubble inflow)
+    over a NaN-poisoned frame == ghost fills one by one (pcl_bc_const / pcl_bc) + pcl_step_hyperbolic.  (A constant
+    cell maps to itself in the frame's index remap: an early version skipped writing it to q.  Found by the
+    multi-process run of tests/test_gpu_multiproc.py.)"""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    mx, my, g = 150, 37, 2
+    rng = np.random.default_rng(77)
+    q0 = np.empty((5, mx, my), order="F")
+    q0[0] = 1 + 0.3 * rng.random((mx, my))
+    q0[1] = 0.3 * rng.standard_normal((mx, my))
+    q0[2] = 0.2 * rng.standard_normal((mx, my))
+    q0[3] = 2.5 + 0.5 * rng.random((mx, my))
+    q0[4] = rng.random((mx, my))
+    inflow = np.array([1.3, 0.4, 0.0, 3.1, 0.0])
+    bc = np.array([0, 1, 3, 1], dtype=np.int32)             # custom (constant), outflow, reflecting, outflow
+    consts = np.zeros(32)
+    consts[0:5] = inflow
+    res = []
+    for fused in (True, False):
+        h = make_unsplit_solver(L, mx, my, False)
+        try:
+            poison = np.full((5, mx + 2 * g, my + 2 * g), np.nan, order="F")
+            L.check(lib.pcl_put_q(h, L.d(poison), 1))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            cfls = []
+            for _ in range(3):
+                cfl = C.c_double()
+                if fused:
+                    L.check(lib.pcl_bc_step(h, L.i(bc), L.d(consts), 1e-4, C.cast(C.byref(cfl), L.dp)))
+                else:
+                    L.check(lib.pcl_bc_const(h, 0, 0, L.d(inflow)))
+                    L.check(lib.pcl_bc(h, 0, 1, 1))
+                    L.check(lib.pcl_bc(h, 1, 0, 3))
+                    L.check(lib.pcl_bc(h, 1, 1, 1))
+                    L.check(lib.pcl_step_hyperbolic(h, 1e-4, C.cast(C.byref(cfl), L.dp)))
+                cfls.append(cfl.value)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            res.append((out, cfls))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and res[0][1][0] > 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
