@@ -354,9 +354,6 @@ def main():
         args.ny = args.nx
         pd = parallel.proc_grid([args.nx, args.nx], size) if size > 1 else [1, 1]
         dims, nxg, nyg = [1] + pd, args.nx, args.nx * pd[0]
-        if args.unsplit and size != 1:
-            sys.stderr.write("bench.py --ndim 3 --unsplit runs on one GPU here\n")
-            sys.exit(2)
         claw = build3d((args.nx, args.nx * pd[0], args.nx * pd[1]), args.math, args.unsplit)
     elif args.app == "sphere":
         if size != 1:

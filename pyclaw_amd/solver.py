@@ -353,7 +353,10 @@ class Solver(object):
         L = _lib.lib()
         import ctypes as C
         import os
-        periodic = [self.bc_lower[k] == BC.periodic for k in range(state.grid.ndim)]
+        # PetClaw's DMDA is periodic in every direction and the physical BCs overwrite the ghost cells of the sides
+        # that are not (petclaw/state.py:205-208): a dimension wraps around as soon as EITHER of its sides is periodic
+        # (the reference's 3-D heterogeneous test has reflecting lower and periodic upper sides)
+        periodic = [self.bc_lower[k] == BC.periodic or self.bc_upper[k] == BC.periodic for k in range(state.grid.ndim)]
         nbr = np.array(dec.neighbors(periodic), dtype=np.int32)
         if os.environ.get("PCL_HALO_TRANSPORT", "rccl") == "host":
             # host-staged wire (diagnostics; several ranks on ONE device): same device path, TCP instead of RCCL

@@ -33,6 +33,10 @@ def run_case(case):
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.06, nout=2, dim_split=0)
     elif case == "acoustics_sharp":
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.03, nout=1, solver_type='sharpclaw')
+    elif case == "acoustics3d_ds":
+        claw = problems.acoustics3D(pyclaw, test='hom', mx=40, my=18, mz=14, tfinal=0.3, nout=1)
+    elif case == "acoustics3d_unsplit":
+        claw = problems.acoustics3D(pyclaw, test='het', mx=24, my=20, mz=16, tfinal=0.3, nout=1)
     else:
         raise SystemExit("unknown case " + case)
     return claw
@@ -48,6 +52,12 @@ def oracle_case(case):
     elif case == "acoustics_sharp":
         p = D.acoustics2d_problem(mx=90, my=80, solver_type='sharpclaw')
         D.run(p, co, 0.03, 1)
+    elif case == "acoustics3d_ds":
+        p = D.acoustics3d_problem('hom', mx=40, my=18, mz=14)
+        D.run(p, co, 0.3, 1)
+    elif case == "acoustics3d_unsplit":
+        p = D.acoustics3d_problem('het', mx=24, my=20, mz=16)
+        D.run(p, co, 0.3, 1)
     else:
         # order_trans: the solver default (trans_inc, clawpack.py:460), which apps/problems.acoustics2D keeps
         p = D.acoustics2d_problem(mx=90, my=80, dim_split=case.endswith("_ds"), order_trans=1)
@@ -72,15 +82,15 @@ def main():
         full = np.full(ref.shape, np.nan)
         for b in blocks:
             q = np.frombuffer(base64.b64decode(b["q"]), dtype=np.float64).reshape(b["shape"])
-            (i0, i1), (j0, j1) = b["rng"]
-            full[:, i0:i1, j0:j1] = q
+            idx = (slice(None),) + tuple(slice(a, b_) for a, b_ in b["rng"])
+            full[idx] = q
         nb = len(set(tuple(map(tuple, b["rng"])) for b in blocks))
         same = np.array_equal(full, ref)
         if not same:
             bad = np.argwhere(~((full == ref) | (np.isnan(full) & np.isnan(ref))))
-            print("mismatches: %d cells; NaN in result %d, in reference %d; first at %s; i range %s j range %s"
+            print("mismatches: %d cells; NaN in result %d, in reference %d; first at %s; index ranges %s"
                   % (len(bad), np.isnan(full).sum(), np.isnan(ref).sum(), bad[:6].tolist(),
-                     (bad[:, 1].min(), bad[:, 1].max()), (bad[:, 2].min(), bad[:, 2].max())))
+                     [(int(bad[:, k].min()), int(bad[:, k].max())) for k in range(1, bad.shape[1])]))
         print("case %s: %d ranks, %d distinct blocks, steps %s, max |diff| %g, bit-identical: %s"
               % (case, size, nb, sorted(set(b["steps"] for b in blocks)), np.nanmax(np.abs(full - ref)), same))
         ok = 0 if (same and nb == size) else 3
