@@ -387,3 +387,45 @@ def burgers_1d(pyclaw, n=400, tfinal=0.5):
     solver.dt_initial = 0.001
     claw.run()
     return claw
+
+
+def rotating_flow(pyclaw, n=64, solver_type='classic', tfinal=0.3, run=True):
+    """Solid-body-like rotation of a blob: colour equation (rp_vc_advection_2d) with edge velocities from a stream
+    function and a capacity function in aux(3) -- the ingredients of apps/advection/2d/annulus on a Cartesian grid --
+    periodic in both directions; classic unsplit (order_trans 2, van Leer) or SharpClaw WENO5."""
+    if solver_type == "classic":
+        solver = pyclaw.ClawSolver2D()
+        solver.dim_split = False
+        solver.order_trans = 2
+        solver.limiters = pyclaw.limiters.tvd.vanleer
+        solver.cfl_max, solver.cfl_desired = 1.0, 0.9
+    else:
+        solver = pyclaw.SharpClawSolver2D()
+        solver.lim_type = 2
+    solver.rp = pyclaw.riemann.rp_vc_advection_2d
+    solver.mwaves = 1
+    for k in range(2):
+        solver.bc_lower[k] = solver.bc_upper[k] = pyclaw.BC.periodic
+        solver.aux_bc_lower[k] = solver.aux_bc_upper[k] = pyclaw.BC.periodic
+    grid = pyclaw.Grid([pyclaw.Dimension('x', -1.0, 1.0, n), pyclaw.Dimension('y', -1.0, 1.0, n)])
+    state = pyclaw.State(grid, 1, 3)
+    state.mcapa = 2
+    d = grid.d[0]
+    xe, ye = grid.x.edge, grid.y.edge
+    psi = lambda x, y: 0.5 * np.pi * (np.cos(np.pi * x / 2) ** 2) * (np.cos(np.pi * y / 2) ** 2)   # stream function
+    XE, YE = np.meshgrid(xe, ye, indexing="ij")
+    P = psi(XE, YE)
+    state.aux[0] = (P[:-1, 1:] - P[:-1, :-1]) / d          # u at the left edge   =  d(psi)/dy
+    state.aux[1] = -(P[1:, :-1] - P[:-1, :-1]) / d         # v at the bottom edge = -d(psi)/dx
+    X, Y = grid.c_center
+    state.aux[2] = 1.0 + 0.2 * np.sin(np.pi * X) * np.sin(np.pi * Y)    # capacity
+    state.q[0] = np.exp(-40.0 * ((X - 0.3) ** 2 + Y ** 2))
+    claw = pyclaw.Controller()
+    claw.keep_copy = True
+    claw.solution = pyclaw.Solution(state)
+    claw.solver = solver
+    claw.tfinal, claw.nout = tfinal, 1
+    solver.dt_initial = 0.005
+    if run:
+        claw.run()
+    return claw

@@ -37,6 +37,8 @@ def run_case(case):
         claw = problems.acoustics3D(pyclaw, test='hom', mx=40, my=18, mz=14, tfinal=0.3, nout=1)
     elif case == "acoustics3d_unsplit":
         claw = problems.acoustics3D(pyclaw, test='het', mx=24, my=20, mz=16, tfinal=0.3, nout=1)
+    elif case.startswith("rotating_"):
+        claw = problems.rotating_flow(pyclaw, n=64, solver_type=case.split("_")[1], tfinal=0.15)
     else:
         raise SystemExit("unknown case " + case)
     return claw
@@ -58,6 +60,30 @@ def oracle_case(case):
     elif case == "acoustics3d_unsplit":
         p = D.acoustics3d_problem('het', mx=24, my=20, mz=16)
         D.run(p, co, 0.3, 1)
+    elif case.startswith("rotating_"):
+        # the serial set-up arrays come from the same app function on an undecomposed grid: build them with numpy here
+        st = case.split("_")[1]
+        n = 64
+        d = 2.0 / n
+        xe = -1.0 + d * np.arange(n + 1)
+        xc = -1.0 + d * (np.arange(n) + 0.5)
+        psi = lambda x, y: 0.5 * np.pi * (np.cos(np.pi * x / 2) ** 2) * (np.cos(np.pi * y / 2) ** 2)
+        XE, YE = np.meshgrid(xe, xe, indexing="ij")
+        P = psi(XE, YE)
+        X, Y = np.meshgrid(xc, xc, indexing="ij")
+        aux = np.empty((3, n, n), order="F")
+        aux[0] = (P[:-1, 1:] - P[:-1, :-1]) / d
+        aux[1] = -(P[1:, :-1] - P[:-1, :-1]) / d
+        aux[2] = 1.0 + 0.2 * np.sin(np.pi * X) * np.sin(np.pi * Y)
+        q0 = np.empty((1, n, n), order="F")
+        q0[0] = np.exp(-40.0 * ((X - 0.3) ** 2 + Y ** 2))
+        kw = (dict(solver_type='sharpclaw', lim_type=2, cfl_max=2.5, cfl_desired=2.45) if st == "sharpclaw"
+              else dict(cfl_max=1.0, cfl_desired=0.9))
+        p = D.Problem(q=q0, aux=aux, rp=O.RP_VC_ADVECTION_2D, rp_params=np.zeros(8), mwaves=1, limiters=3,
+                      bc_lower=[D.PERIODIC] * 2, bc_upper=[D.PERIODIC] * 2, aux_bc_lower=[D.PERIODIC] * 2,
+                      aux_bc_upper=[D.PERIODIC] * 2, d=(d, d), dim_split=False, order_trans=2, mcapa=2,
+                      dt_initial=0.005, **kw)
+        D.run(p, co, 0.15, 1)
     else:
         # order_trans: the solver default (trans_inc, clawpack.py:460), which apps/problems.acoustics2D keeps
         p = D.acoustics2d_problem(mx=90, my=80, dim_split=case.endswith("_ds"), order_trans=1)
