@@ -142,7 +142,7 @@ def ac2d_qinit(state, width=0.2):
 
 
 def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=True, math='exact',
-                solver_type='classic', lim_type=2, time_integrator='SSP104'):
+                solver_type='classic', lim_type=2, time_integrator='SSP104', weno_order=5):
     """test/acoustics/2d/homogeneous/acoustics.py:19-86 (classic or sharpclaw)."""
     if solver_type == 'classic':
         solver = pyclaw.ClawSolver2D()
@@ -150,6 +150,7 @@ def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=T
         solver = pyclaw.SharpClawSolver2D()
         solver.lim_type = lim_type
         solver.time_integrator = time_integrator
+        solver.weno_order = weno_order
     solver.math = math
     solver.rp = pyclaw.riemann.rp_acoustics_2d
     solver.cfl_max = 0.5

@@ -33,6 +33,9 @@ def run_case(case):
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.06, nout=2, dim_split=0)
     elif case == "acoustics_sharp":
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.03, nout=1, solver_type='sharpclaw')
+    elif case == "acoustics_sharp9":
+        claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.03, nout=1, solver_type='sharpclaw', weno_order=9,
+                                    time_integrator='SSP33')
     elif case == "acoustics3d_ds":
         claw = problems.acoustics3D(pyclaw, test='hom', mx=40, my=18, mz=14, tfinal=0.3, nout=1)
     elif case == "acoustics3d_unsplit":
@@ -53,6 +56,9 @@ def oracle_case(case):
         D.run(p, co, 0.03, 1)
     elif case == "acoustics_sharp":
         p = D.acoustics2d_problem(mx=90, my=80, solver_type='sharpclaw')
+        D.run(p, co, 0.03, 1)
+    elif case == "acoustics_sharp9":
+        p = D.acoustics2d_problem(mx=90, my=80, solver_type='sharpclaw', weno_order=9, time_integrator='SSP33')
         D.run(p, co, 0.03, 1)
     elif case == "acoustics3d_ds":
         p = D.acoustics3d_problem('hom', mx=40, my=18, mz=14)
