@@ -27,6 +27,8 @@ def run_case(case):
         claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=True)
     elif case == "shockbubble_unsplit":
         claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=True, dim_split=False)
+    elif case == "shockbubble_pycb":         # the reference app's own Python callbacks: custom-BC strips + numpy source term
+        claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=False)
     elif case == "acoustics_ds":
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.06, nout=2)
     elif case == "acoustics_unsplit":
@@ -52,7 +54,7 @@ def oracle_case(case):
     from oracle import oracle as O
     co = O.COracle()
     if case.startswith("shockbubble"):
-        p = D.shockbubble_problem(mx=160, my=40, dim_split=case.endswith("_ds"))
+        p = D.shockbubble_problem(mx=160, my=40, dim_split=not case.endswith("_unsplit"))
         D.run(p, co, 0.03, 1)
     elif case == "acoustics_sharp":
         p = D.acoustics2d_problem(mx=90, my=80, solver_type='sharpclaw')
