@@ -356,14 +356,16 @@ def main():
         dims, nxg, nyg = [1] + pd, args.nx, args.nx * pd[0]
         claw = build3d((args.nx, args.nx * pd[0], args.nx * pd[1]), args.math, args.unsplit)
     elif args.app == "sphere":
-        if size != 1:
-            sys.stderr.write("bench.py --app sphere runs on one GPU here (the pole boundary mirrors whole rows)\n")
-            sys.exit(2)
+        # BASELINE configs[4]: the GLOBAL grid is fixed (2048 x 1024) and cut in y only, 1 x N blocks -- the pole
+        # boundary reverses whole rows (strong scaling)
         if args.nx == 4096:
             args.nx = 2048
         args.ny = args.nx // 2
-        dims, nxg, nyg = [1, 1], args.nx, args.ny
+        scaling = "strong" if size > 1 else "weak"
+        os.environ["PCL_PROC_GRID"] = "1x%d" % size
+        dims, nxg, nyg = [1, size], args.nx, args.ny
         claw = build_sphere(nxg, nyg, args.math, args.solver)
+        args.nx, args.ny = claw.solution.state.q.shape[1:3]          # THIS rank's block (rank 0 prints)
     elif args.solver == "sharpclaw":
         # weak scaling like the classic line: nx x ny cells per GPU; every stage's halo exchange overlaps the
         # interior tiles of its x pass (pcl_sharp_bc_stage)

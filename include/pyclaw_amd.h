@@ -210,6 +210,9 @@ int pcl_bc_aux(pcl_solver *s, int idim, int side, int bctype);
  * Python that only touch the strip (user_bc_lower/upper, solver.py:404-405,439-440). */
 int pcl_get_strip(pcl_solver *s, int idim, int side, int width, double *host);
 int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *host);
+/* the aux twin of pcl_put_strip: a ghost strip of auxbc filled by a Python aux-BC callback (user_aux_bc_lower/upper,
+ * solver.py:526-596), placed after the aux halo exchange of a decomposed run */
+int pcl_put_aux_strip(pcl_solver *s, int idim, int side, int width, const double *host);
 /* Gauges (Solver.write_gauge_values, solver.py:731-741: q[:,x,y] and aux[:,x,y] of a few cells
  * after every step): gather `ncell` interior cells (0-based interior indices ij[2*c], ij[2*c+1];
  * the second is ignored in 1-D) of the resident q -- and of aux when `aux` is not NULL -- into

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "pcl_bc_aux": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pcl_get_strip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]),
     "pcl_put_strip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]),
+    "pcl_put_aux_strip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]),
     "pcl_get_cells": (C.c_int, [C.c_void_p, C.c_int, ip, dp, dp]),
     "pcl_step_hyperbolic": (C.c_int, [C.c_void_p, C.c_double, dp]),
     "pcl_undo_step": (C.c_int, [C.c_void_p]),

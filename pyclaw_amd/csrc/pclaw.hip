@@ -834,6 +834,23 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
     return PCL_OK;
 }
 
+// the same for the aux array: a ghost strip computed by a Python aux-BC callback on the host (decomposed runs)
+int pcl_put_aux_strip(pcl_solver *s, int idim, int side, int width, const double *host) {
+    if (!s || !host) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.maux <= 0 || !s->aux) return fail(PCL_ESTATE, "pcl_put_aux_strip: no aux array on the device");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    int ni, nj, io, jo;
+    if (int rc = strip_window(s, idim, side, width, ni, nj, io, jo)) return rc;
+    const int nm = s->cfg.maux;
+    if ((size_t)nm * ni * nj * sizeof(double) > s->stage_bytes) return fail(PCL_EINVAL, "pcl_put_aux_strip: strip exceeds the staging buffer");
+    HIP_TRY(hipMemcpyAsync(s->stage, host, (size_t)nm * ni * nj * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    dim3 grid((ni + 255) / 256, nj);
+    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, s->aux, nm, ni, nj, io, jo, s->pitch, s->plane);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PCL_OK;
+}
+
 __global__ void gather_cells_kernel(const double *q, const double *aux, const int *ij, double *out, int ncell,
                                     int nq, int na, int mbc, int ndim, long pitch, long plane) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -307,6 +307,12 @@ def proc_grid(n_global, size):
         return [size]
     if len(n_global) == 2:
         M, Ncells = n_global
+        forced = os.environ.get("PCL_PROC_GRID")      # "PXxPY" (PETSc: -da_processors_x / _y)
+        if forced:
+            m, n = (int(v) for v in forced.lower().split("x"))
+            if m * n != size or M < m or Ncells < n:
+                raise Exception("PCL_PROC_GRID=%s does not fit %d processes on a %dx%d grid" % (forced, size, M, Ncells))
+            return [m, n]
         m = int(0.5 + math.sqrt(float(M) * float(size) / float(Ncells)))
         m = max(1, min(m, size))
         while m > 0 and size % m:

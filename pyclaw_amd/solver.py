@@ -64,6 +64,9 @@ class SphereMirrorBC(DeviceBC):
     def apply(self, solver, idim, side):
         if idim != 1:
             raise Exception("SphereMirrorBC is the y boundary of a 2-D grid")
+        dec = getattr(solver, '_state', None) and solver._state.decomp
+        if dec is not None and dec.dims[0] != 1:
+            raise Exception("SphereMirrorBC reverses whole rows: decompose the grid in y only (PCL_PROC_GRID=1xN)")
         _lib.check(_lib.lib().pcl_bc(solver._h, idim, side, 4))
 
 
@@ -336,7 +339,17 @@ class Solver(object):
                     continue
                 bc = bcs[idim]
                 if bc == BC.custom:
-                    raise NotImplementedError("custom aux BCs are not supported on a decomposed grid")
+                    # the callback filled these ghost layers of the host auxbc (apply_aux_bcs), over the whole
+                    # ghosted width of the block; they go onto the device at the callback's place in the reference
+                    # order (exchange, then per dimension lower / upper).  Right as long as the callback computes
+                    # them from positions alone, like the sphere app's setaux rows: one that copies interior values
+                    # would miss the exchanged cells next to a neighbour face.
+                    idx = [slice(None)] * self.auxbc.ndim
+                    idx[idim + 1] = (slice(0, self.mbc) if side == 0
+                                     else slice(self.auxbc.shape[idim + 1] - self.mbc, None))
+                    strip = np.asfortranarray(self.auxbc[tuple(idx)])
+                    _lib.check(L.pcl_put_aux_strip(self._h, idim, side, self.mbc, _lib.d(strip)))
+                    continue
                 if bc == BC.periodic and not whole:
                     continue
                 _lib.check(L.pcl_bc_aux(self._h, idim, side, bc))

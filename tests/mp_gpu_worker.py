@@ -23,6 +23,16 @@ from apps import problems                   # noqa: E402
 
 
 def run_case(case):
+    if case == "sphere_classic":
+        # C5's physics on several ranks: blocks cut in y only (the pole boundary reverses whole rows); set-up arrays
+        # from the C restatement of the app's setaux.f / qinit.f so that the serial oracle replay starts from the same bits
+        from apps import shallow_sphere as S
+        from oracle import oracle as O
+        co = O.COracle()
+        mx, my = 40, 20
+        aux = co.sphere_setaux(2, mx, my, -3.0, -1.0, 4.0 / mx, 2.0 / my)
+        q0 = co.sphere_qinit(2, mx, my, -3.0, -1.0, 4.0 / mx, 2.0 / my)[:, 2:-2, 2:-2]
+        return S.shallow_sphere(pyclaw, mx, my, tfinal=2.0, nout=2, aux_full=aux, q0=q0)
     if case == "shockbubble_ds":
         claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=True)
     elif case == "shockbubble_unsplit":
@@ -53,6 +63,10 @@ def oracle_case(case):
     from oracle import driver as D
     from oracle import oracle as O
     co = O.COracle()
+    if case == "sphere_classic":
+        p = D.shallow_sphere_problem(co)
+        D.run(p, co, 2.0, 2)
+        return p.q, p
     if case.startswith("shockbubble"):
         p = D.shockbubble_problem(mx=160, my=40, dim_split=not case.endswith("_unsplit"))
         D.run(p, co, 0.03, 1)
@@ -101,6 +115,8 @@ def oracle_case(case):
 
 def main():
     case = sys.argv[1]
+    if case.startswith("sphere"):
+        os.environ["PCL_PROC_GRID"] = "1x%s" % os.environ.get("WORLD_SIZE", "1")
     parallel.init()
     rank, size = parallel.rank(), parallel.world_size()
     claw = run_case(case)

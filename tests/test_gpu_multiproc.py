@@ -55,7 +55,8 @@ def launch(case, nranks, overlap=None):
                                          ("acoustics_unsplit", 3), ("acoustics3d_ds", 4), ("acoustics3d_ds", 2),
                                          ("acoustics3d_unsplit", 4), ("acoustics3d_unsplit", 2),
                                          ("rotating_classic", 4), ("rotating_classic", 2), ("rotating_sharpclaw", 4),
-                                         ("acoustics_sharp9", 4), ("shockbubble_pycb", 2), ("shockbubble_pycb", 4)])
+                                         ("acoustics_sharp9", 4), ("shockbubble_pycb", 2), ("shockbubble_pycb", 4),
+                                         ("sphere_classic", 2), ("sphere_classic", 4)])
 def test_decomposed_device_run_equals_serial(case, nranks):
     launch(case, nranks)
 
