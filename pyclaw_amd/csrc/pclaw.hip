@@ -453,8 +453,17 @@ __global__ void frame_kernel(double *q, double *dst, int nm, int I, int J, int m
         if (i >= mbc && i < I - mbc && j >= mbc && j < J - mbc) continue;
         int si, sj, sdi, sdj;
         bool ni, nj, ci, cj;
-        frame_map(i, I, mbc, f.t[0], f.t[1], si, ni, ci, sdi);
-        frame_map(j, J, mbc, f.t[2], f.t[3], sj, nj, cj, sdj);
+        // y first (the side applied LAST): the sphere app's pole boundary also reverses the row over its whole ghosted
+        // width (bc_sphere_mirror), so the x rule then applies to the reversed column
+        int ix = i;
+        const bool mir_lo = j < mbc && f.t[2] == PCL_BC_SPHERE_MIRROR, mir_hi = j >= J - mbc && f.t[3] == PCL_BC_SPHERE_MIRROR;
+        if (mir_lo || mir_hi) {
+            sj = mir_lo ? 2 * mbc - 1 - j : 2 * (J - mbc) - 1 - j;
+            nj = false; cj = false; sdj = mir_lo ? 0 : 1;
+            ix = I - 1 - i;
+        } else
+            frame_map(j, J, mbc, f.t[2], f.t[3], sj, nj, cj, sdj);
+        frame_map(ix, I, mbc, f.t[0], f.t[1], si, ni, ci, sdi);
         const long g = (long)j * pitch + i, gs = (long)sj * pitch + si;
         for (int m = 0; m < nm; m++) {
             double v = q[m * plane + gs];
@@ -1002,6 +1011,11 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     HIP_TRY(hipSetDevice(s->cfg.device));
     for (int k = 0; k < 2 * s->cfg.ndim; k++) {
         const int t = bc[k];
+        if (t == PCL_BC_SPHERE_MIRROR) {       // the sphere app's pole boundary: y sides of the unsplit 2-D step
+            if (s->cfg.ndim != 2 || k < 2 || s->cfg.method[2] < 0)
+                return fail(PCL_EINVAL, "PCL_BC_SPHERE_MIRROR in pcl_bc_step: y sides of the unsplit 2-D step only");
+            continue;
+        }
         if (t >= 0 && t != PCL_BC_CUSTOM && t != PCL_BC_OUTFLOW && t != PCL_BC_PERIODIC && t != PCL_BC_REFLECTING)
             return fail(PCL_EINVAL, "bad boundary condition type");
         if (t == PCL_BC_CUSTOM && !cstate) return fail(PCL_EINVAL, "constant state missing");
@@ -1212,6 +1226,13 @@ static int sharp_frame(pcl_solver *s, const int *bc, const double *cstate, hipSt
         for (int side = 0; side < 2; side++) {
             const int t = bc[2 * idim + side];
             if (t < 0) continue;
+            if (t == PCL_BC_SPHERE_MIRROR) {
+                const long n = (long)s->I * s->cfg.mbc * s->cfg.meqn;
+                hipLaunchKernelGGL(bc_sphere_mirror, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cur(s),
+                                   s->cfg.meqn, s->I, s->J, s->pitch, s->plane, s->cfg.mbc, side);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
             const int rc = t == PCL_BC_CUSTOM
                                ? bc_launch(s, idim, side, 100, cstate + (2 * idim + side) * PCL_MAX_RP_PARAMS, false, stream)
                                : bc_launch(s, idim, side, t, nullptr, false, stream);
@@ -1260,6 +1281,10 @@ static int sharp_passes(pcl_solver *s, double dt, int rk_op, const double *ra, c
 static int check_bc_spec(pcl_solver *s, const int *bc, const double *cstate) {
     for (int k = 0; k < 2 * s->cfg.ndim; k++) {
         const int t = bc[k];
+        if (t == PCL_BC_SPHERE_MIRROR) {
+            if (s->cfg.ndim != 2 || k < 2) return fail(PCL_EINVAL, "PCL_BC_SPHERE_MIRROR is the y boundary of a 2-D grid");
+            continue;
+        }
         if (t >= 0 && t != PCL_BC_CUSTOM && t != PCL_BC_OUTFLOW && t != PCL_BC_PERIODIC && t != PCL_BC_REFLECTING)
             return fail(PCL_EINVAL, "bad boundary condition type");
         if (t == PCL_BC_CUSTOM && !cstate) return fail(PCL_EINVAL, "constant state missing");

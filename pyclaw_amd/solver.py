@@ -241,6 +241,9 @@ class Solver(object):
                         if fn.dims is None or idim in fn.dims:
                             types[k] = BC.custom
                             consts[k * _lib.MAX_RP_PARAMS:k * _lib.MAX_RP_PARAMS + state.meqn] = fn.state
+                    elif (isinstance(fn, SphereMirrorBC) and self.ndim == 2 and idim == 1 and self._mirror_in_spec()
+                          and (state.decomp is None or state.decomp.dims[0] == 1)):
+                        types[k] = 4                       # PCL_BC_SPHERE_MIRROR
                     else:
                         spec = None
                 elif bc == BC.periodic:
@@ -255,6 +258,11 @@ class Solver(object):
             spec = (types, consts, _lib.i(types), _lib.d(consts))
         self._bc_spec_cache = (key, spec)
         return spec
+
+    def _mirror_in_spec(self):
+        """the library takes the sphere app's pole boundary inside pcl_bc_step (unsplit classic step) and inside the
+        SharpClaw stage calls; the dimension-split classic step evaluates its BCs in the x pass and does not"""
+        return getattr(self, 'lim_type', None) is not None or not getattr(self, 'dim_split', True)
 
     def _custom_bc(self, state, dim, idim, side, fn):
         if fn is None:
