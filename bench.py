@@ -338,6 +338,9 @@ def main():
     args = ap.parse_args()
 
     from pyclaw_amd import parallel, _lib
+    # a multi-GPU run whose RCCL set-up fails on this node still produces a (slow, clearly labelled) line over the
+    # host-staged halo wire instead of no line at all: config.halo_transport says which wire ran
+    os.environ.setdefault("PCL_HALO_FALLBACK", "host")
     parallel.init()
     rank, size = parallel.rank(), parallel.world_size()
     if size != args.gpus:
@@ -453,6 +456,7 @@ def main():
                                    % (grid_note, "UNSPLIT order_trans=2" if args.unsplit else "dim-split"),
                        "global_grid": [nxg, nyg] + ([args.nx * dims[2]] if args.ndim == 3 else []), "proc_grid": dims, "math": ("exact (no FMA, IEEE div/sqrt; bit-identical to the reference)" if args.math == "exact"
                                 else "fast (FMA contraction, reciprocal-multiply division; rtol 1e-12 vs reference)"),
+                       "halo_transport": getattr(claw.solver, "halo_transport", "none (one block)"),
                        "launches_timed": {names[0]: int(nl[0]), names[1]: int(nl[1])},
                        "steps_incl_rejected": int(attempted), "result_finite": finite},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -223,6 +223,14 @@ def broadcast_bytes(data, src=0):
     return bytes.fromhex(vals[src])
 
 
+def allgather(value):
+    """Every rank's small JSON-able value, in rank order (a list of one for a single process)."""
+    g = _state["group"]
+    if g is None:
+        return [value]
+    return g.allgather(value)
+
+
 def allreduce_max_host(value):
     """Host-side max all-reduce (bench timing, CPU tests).  The solver's CFL uses RCCL."""
     g = _state["group"]

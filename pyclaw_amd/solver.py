@@ -379,21 +379,45 @@ class Solver(object):
         # (the reference's 3-D heterogeneous test has reflecting lower and periodic upper sides)
         periodic = [self.bc_lower[k] == BC.periodic or self.bc_upper[k] == BC.periodic for k in range(state.grid.ndim)]
         nbr = np.array(dec.neighbors(periodic), dtype=np.int32)
-        if os.environ.get("PCL_HALO_TRANSPORT", "rccl") == "host":
-            # host-staged wire (diagnostics; several ranks on ONE device): same device path, TCP instead of RCCL
+        def host_wire():
+            # host-staged wire: same device path, this module's TCP group instead of RCCL
             self._host_transport = parallel.host_transport()
             xfn, rfn = self._host_transport
             _lib.check(L.pcl_comm_init_host(self._h, parallel.world_size(), parallel.rank(), _lib.i(nbr),
                                             C.cast(xfn, C.c_void_p), C.cast(rfn, C.c_void_p), None))
             self._halo_active = True
             self.cfl._reduce = None
-            return
+
+        if os.environ.get("PCL_HALO_TRANSPORT", "rccl") == "host":     # diagnostics; several ranks on ONE device
+            self.halo_transport = "host"
+            return host_wire()
+        # RCCL.  Every rank learns whether EVERY rank got its communicator (a failure on one rank -- librccl missing,
+        # ncclCommInitRank refusing -- must not leave the others waiting inside a collective).
+        err = None
         uid = C.create_string_buffer(128)
-        if parallel.rank() == 0:
+        try:                                  # on every rank: loads librccl (rank 0's id is the one that is used)
             _lib.check(L.pcl_comm_unique_id(uid))
-        raw = parallel.broadcast_bytes(uid.raw if parallel.rank() == 0 else None, src=0)
-        uid = C.create_string_buffer(raw, 128)
-        _lib.check(L.pcl_comm_init(self._h, parallel.world_size(), parallel.rank(), uid, _lib.i(nbr)))
+        except _lib.PclError as e:
+            err = str(e)
+        loaded = [e for e in parallel.allgather(err) if e]      # nobody enters ncclCommInitRank unless all can
+        raw = parallel.broadcast_bytes((uid.raw if not loaded else b"") if parallel.rank() == 0 else None, src=0)
+        if len(raw) != 128:
+            err = err or loaded[0]
+        else:
+            try:
+                _lib.check(L.pcl_comm_init(self._h, parallel.world_size(), parallel.rank(),
+                                           C.create_string_buffer(raw, 128), _lib.i(nbr)))
+            except _lib.PclError as e:
+                err = str(e)
+        errs = [e for e in parallel.allgather(err) if e]
+        if errs:
+            if os.environ.get("PCL_HALO_FALLBACK", "") != "host":
+                raise Exception("RCCL communicator set-up failed on %d rank(s): %s  (PCL_HALO_FALLBACK=host would "
+                                "run the same device path over the host-staged wire)" % (len(errs), errs[0]))
+            self.logger.warning("RCCL set-up failed (%s): falling back to the host-staged halo wire" % errs[0])
+            self.halo_transport = "host (fallback: RCCL set-up failed: %s)" % errs[0]
+            return host_wire()
+        self.halo_transport = "rccl"
         self._halo_active = True
         # the CFL all-reduce (petclaw/cfl.py:29-31) happens inside pcl_step_hyperbolic /
         # pcl_sharp_dq on the device: the value they return is already the global maximum
