@@ -39,6 +39,8 @@ def run_case(case):
         claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=True, dim_split=False)
     elif case == "shockbubble_pycb":         # the reference app's own Python callbacks: custom-BC strips + numpy source term
         claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=False)
+    elif case == "acoustics_odd":            # sizes that do not divide: blocks of unequal width (PETSc: remainder first)
+        claw = problems.acoustics2D(pyclaw, mx=91, my=83, tfinal=0.06, nout=2, dim_split=0)
     elif case == "acoustics_ds":
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.06, nout=2)
     elif case == "acoustics_unsplit":
@@ -76,6 +78,9 @@ def oracle_case(case):
     elif case == "acoustics_sharp9":
         p = D.acoustics2d_problem(mx=90, my=80, solver_type='sharpclaw', weno_order=9, time_integrator='SSP33')
         D.run(p, co, 0.03, 1)
+    elif case == "acoustics_odd":
+        p = D.acoustics2d_problem(mx=91, my=83, dim_split=False, order_trans=1)
+        D.run(p, co, 0.06, 2)
     elif case == "acoustics3d_ds":
         p = D.acoustics3d_problem('hom', mx=40, my=18, mz=14)
         D.run(p, co, 0.3, 1)

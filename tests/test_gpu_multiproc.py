@@ -56,7 +56,8 @@ def launch(case, nranks, overlap=None):
                                          ("acoustics3d_unsplit", 4), ("acoustics3d_unsplit", 2),
                                          ("rotating_classic", 4), ("rotating_classic", 2), ("rotating_sharpclaw", 4),
                                          ("acoustics_sharp9", 4), ("shockbubble_pycb", 2), ("shockbubble_pycb", 4),
-                                         ("sphere_classic", 2), ("sphere_classic", 4)])
+                                         ("sphere_classic", 2), ("sphere_classic", 4),
+                                         ("acoustics_odd", 5), ("acoustics_odd", 3), ("acoustics_odd", 4)])
 def test_decomposed_device_run_equals_serial(case, nranks):
     launch(case, nranks)
 
