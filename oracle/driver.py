@@ -343,7 +343,7 @@ GAMMA1 = GAMMA - 1.0
 
 
 def shockbubble_problem(mx=160, my=40, with_src=True, dim_split=True, order_trans=2,
-                        dt_initial=0.005):
+                        dt_initial=0.005, **kw):
     """test/euler/2d/shockbubble.py:9-146 (qinit, auxinit, shockbc, euler_rad_src, solver setup)."""
     from oracle.oracle import RP_EULER5_2D
     gamma, gamma1 = GAMMA, GAMMA1
@@ -403,7 +403,7 @@ def shockbubble_problem(mx=160, my=40, with_src=True, dim_split=True, order_tran
         bc_lower=[CUSTOM, REFLECTING], bc_upper=[OUTFLOW, OUTFLOW], user_bc_lower=shockbc,
         aux_bc_lower=[OUTFLOW, OUTFLOW], aux_bc_upper=[OUTFLOW, OUTFLOW],
         step_src=euler_rad_src if with_src else None, src_split=1,
-        dim_split=dim_split, order_trans=order_trans)
+        dim_split=dim_split, order_trans=order_trans, **kw)
 
 
 def acoustics2d_problem(mx=100, my=100, dim_split=True, order_trans=2, bcs=None, **kw):

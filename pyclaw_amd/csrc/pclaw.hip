@@ -305,6 +305,58 @@ int drain_timing(pcl_solver *s) {
     return PCL_OK;
 }
 
+// Ghost frame of the unsplit step in ONE launch: every cell outside the interior gets its boundary value -- the
+// composition of the per-side fills of solver.py:354-452 (x sides first, then y sides over the x-filled columns, so a
+// corner cell is the y rule applied to an x-ghost cell) written as an index remap, like the dim-split x pass does
+// while loading its tiles -- and is copied to dst (the y phase updates t1 in place and its ghost frame must equal
+// qold's).  bc[k] < 0: no fill on that side (neighbour block or a fill done elsewhere); 100 = constant state.
+struct FrameBc { int t[4]; double c[4][8]; };
+__device__ __forceinline__ void frame_map(int k, int n, int mbc, int lo, int hi, int &src, bool &neg, bool &cst, int &side) {
+    src = k; neg = false; cst = false; side = 0;
+    if (k < mbc && lo >= 0) {
+        if (lo == PCL_BC_OUTFLOW) src = mbc;
+        else if (lo == PCL_BC_PERIODIC) src = n - 2 * mbc + k;
+        else if (lo == PCL_BC_REFLECTING) { src = 2 * mbc - 1 - k; neg = true; }
+        else cst = true;
+    } else if (k >= n - mbc && hi >= 0) {
+        side = 1;
+        if (hi == PCL_BC_OUTFLOW) src = n - mbc - 1;
+        else if (hi == PCL_BC_PERIODIC) src = k - (n - 2 * mbc);
+        else if (hi == PCL_BC_REFLECTING) { src = 2 * (n - mbc) - 1 - k; neg = true; }
+        else cst = true;
+    }
+}
+__global__ void frame_kernel(double *q, double *dst, int nm, int I, int J, int mbc, long pitch, long plane, FrameBc f) {
+    const long ncell = (long)I * J;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell; t += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(t % I), j = (int)(t / I);
+        if (i >= mbc && i < I - mbc && j >= mbc && j < J - mbc) continue;
+        int si, sj, sdi, sdj;
+        bool ni, nj, ci, cj;
+        // y first (the side applied LAST): the sphere app's pole boundary also reverses the row over its whole ghosted
+        // width (bc_sphere_mirror), so the x rule then applies to the reversed column
+        int ix = i;
+        const bool mir_lo = j < mbc && f.t[2] == PCL_BC_SPHERE_MIRROR, mir_hi = j >= J - mbc && f.t[3] == PCL_BC_SPHERE_MIRROR;
+        if (mir_lo || mir_hi) {
+            sj = mir_lo ? 2 * mbc - 1 - j : 2 * (J - mbc) - 1 - j;
+            nj = false; cj = false; sdj = mir_lo ? 0 : 1;
+            ix = I - 1 - i;
+        } else
+            frame_map(j, J, mbc, f.t[2], f.t[3], sj, nj, cj, sdj);
+        frame_map(ix, I, mbc, f.t[0], f.t[1], si, ni, ci, sdi);
+        const long g = (long)j * pitch + i, gs = (long)sj * pitch + si;
+        for (int m = 0; m < nm; m++) {
+            double v = q[m * plane + gs];
+            if (m == 1) v = ni ? -v : v;
+            v = ci ? f.c[sdi][m < 8 ? m : 7] : v;
+            if (m == 2) v = nj ? -v : v;
+            v = cj ? f.c[2 + sdj][m < 8 ? m : 7] : v;
+            if (gs != g || ci || cj) q[m * plane + g] = v;      // (a constant-state cell maps to itself)
+            if (dst) dst[m * plane + g] = v;
+        }
+    }
+}
+
 // one directional sweep qin -> qout; ids 1 = x (or the 1-D step), 2 = y
 // sub/box: tile subset of the x pass (sweep_args.hpp); the second launch of a split pass adds its time to
 // the pass without counting as another launch
@@ -314,6 +366,15 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
     SweepArgs a = make_args(s, qin, qout, ids, dt);
     a.sub = sub;
     if (sub) for (int k = 0; k < 4; k++) a.box[k] = box[k];
+    if (s->cfg.mbc > 2 && s->cfg.ndim <= 2 && sub != 2) {
+        // more than two ghost layers: the sweep kernels copy through the two layers their strips hold; the outer
+        // layers of qnew are copies of qold as well (step2ds.f / step1.f update interior cells of a copy)
+        FrameBc f;
+        for (int k = 0; k < 4; k++) { f.t[k] = -1; for (int m = 0; m < 8; m++) f.c[k][m] = 0.0; }
+        hipLaunchKernelGGL(frame_kernel, dim3(256), dim3(256), 0, stream, const_cast<double *>(qin), qout, s->cfg.meqn,
+                           s->I, s->J, s->cfg.mbc, s->pitch, s->plane, f);
+        HIP_TRY(hipGetLastError());
+    }
     pcl_solver::Timed t{};
     const bool timed = timing_on(s) && !on;  // a launch on the halo stream runs beside the interior: not timed
     if (timed) {
@@ -423,58 +484,6 @@ int do_unsplit3(pcl_solver *s, double dt) {
         if (rc) return fail(rc, err);
     }
     return PCL_OK;
-}
-
-// Ghost frame of the unsplit step in ONE launch: every cell outside the interior gets its boundary value -- the
-// composition of the per-side fills of solver.py:354-452 (x sides first, then y sides over the x-filled columns, so a
-// corner cell is the y rule applied to an x-ghost cell) written as an index remap, like the dim-split x pass does
-// while loading its tiles -- and is copied to dst (the y phase updates t1 in place and its ghost frame must equal
-// qold's).  bc[k] < 0: no fill on that side (neighbour block or a fill done elsewhere); 100 = constant state.
-struct FrameBc { int t[4]; double c[4][8]; };
-__device__ __forceinline__ void frame_map(int k, int n, int mbc, int lo, int hi, int &src, bool &neg, bool &cst, int &side) {
-    src = k; neg = false; cst = false; side = 0;
-    if (k < mbc && lo >= 0) {
-        if (lo == PCL_BC_OUTFLOW) src = mbc;
-        else if (lo == PCL_BC_PERIODIC) src = n - 2 * mbc + k;
-        else if (lo == PCL_BC_REFLECTING) { src = 2 * mbc - 1 - k; neg = true; }
-        else cst = true;
-    } else if (k >= n - mbc && hi >= 0) {
-        side = 1;
-        if (hi == PCL_BC_OUTFLOW) src = n - mbc - 1;
-        else if (hi == PCL_BC_PERIODIC) src = k - (n - 2 * mbc);
-        else if (hi == PCL_BC_REFLECTING) { src = 2 * (n - mbc) - 1 - k; neg = true; }
-        else cst = true;
-    }
-}
-__global__ void frame_kernel(double *q, double *dst, int nm, int I, int J, int mbc, long pitch, long plane, FrameBc f) {
-    const long ncell = (long)I * J;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell; t += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(t % I), j = (int)(t / I);
-        if (i >= mbc && i < I - mbc && j >= mbc && j < J - mbc) continue;
-        int si, sj, sdi, sdj;
-        bool ni, nj, ci, cj;
-        // y first (the side applied LAST): the sphere app's pole boundary also reverses the row over its whole ghosted
-        // width (bc_sphere_mirror), so the x rule then applies to the reversed column
-        int ix = i;
-        const bool mir_lo = j < mbc && f.t[2] == PCL_BC_SPHERE_MIRROR, mir_hi = j >= J - mbc && f.t[3] == PCL_BC_SPHERE_MIRROR;
-        if (mir_lo || mir_hi) {
-            sj = mir_lo ? 2 * mbc - 1 - j : 2 * (J - mbc) - 1 - j;
-            nj = false; cj = false; sdj = mir_lo ? 0 : 1;
-            ix = I - 1 - i;
-        } else
-            frame_map(j, J, mbc, f.t[2], f.t[3], sj, nj, cj, sdj);
-        frame_map(ix, I, mbc, f.t[0], f.t[1], si, ni, ci, sdi);
-        const long g = (long)j * pitch + i, gs = (long)sj * pitch + si;
-        for (int m = 0; m < nm; m++) {
-            double v = q[m * plane + gs];
-            if (m == 1) v = ni ? -v : v;
-            v = ci ? f.c[sdi][m < 8 ? m : 7] : v;
-            if (m == 2) v = nj ? -v : v;
-            v = cj ? f.c[2 + sdj][m < 8 ? m : 7] : v;
-            if (gs != g || ci || cj) q[m * plane + g] = v;      // (a constant-state cell maps to itself)
-            if (dst) dst[m * plane + g] = v;
-        }
-    }
 }
 
 static int unsplit_frame(pcl_solver *s, hipStream_t stream, const int *bc = nullptr, const double *cstate = nullptr) {
@@ -602,8 +611,12 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     }
     *out = nullptr;
     if (cfg->ndim < 1 || cfg->ndim > 3) return fail(PCL_EINVAL, "ndim must be 1, 2 or 3");
-    if (cfg->kind == PCL_KIND_CLASSIC && cfg->mbc != 2)
-        return fail(PCL_EINVAL, "classic kernels need mbc == 2 (reference default)");
+    // the reference's default is 2 (the limiter reaches two cells); more ghost layers only widen the frame that the
+    // sweeps copy through / sweep over (step2ds.f sweeps every ghost row), the strips keep their 2-cell halo
+    if (cfg->kind == PCL_KIND_CLASSIC && (cfg->mbc < 2 || cfg->mbc > 8))
+        return fail(PCL_EINVAL, "classic kernels need 2 <= mbc <= 8");
+    if (cfg->kind == PCL_KIND_CLASSIC && cfg->ndim == 3 && cfg->mbc != 2)
+        return fail(PCL_EINVAL, "3-D classic kernels need mbc == 2 (reference default)");
     // mbc = (weno_order+1)/2 (sharpclaw.py:479): 3 for tvd2 / WENO5 / legacy WENO5, 4..9 = weno_order 7..17 (lim_type 2)
     if (cfg->kind == PCL_KIND_SHARPCLAW && (cfg->mbc < 3 || cfg->mbc > 9))
         return fail(PCL_EINVAL, "SharpClaw: mbc = (weno_order+1)/2 must be 3..9 (weno_order 5..17)");
