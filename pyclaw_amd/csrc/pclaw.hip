@@ -311,6 +311,11 @@ int drain_timing(pcl_solver *s) {
 // while loading its tiles -- and is copied to dst (the y phase updates t1 in place and its ghost frame must equal
 // qold's).  bc[k] < 0: no fill on that side (neighbour block or a fill done elsewhere); 100 = constant state.
 struct FrameBc { int t[4]; double c[4][8]; };
+static inline unsigned frame_blocks(const pcl_solver *s) {      // one thread per ghost cell, at most 256 workgroups
+    const long n = s->J > 2 * s->cfg.mbc ? 2L * s->cfg.mbc * (s->I + s->J - 2 * s->cfg.mbc) : (long)s->I * s->J;
+    const long b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
 __device__ __forceinline__ void frame_map(int k, int n, int mbc, int lo, int hi, int &src, bool &neg, bool &cst, int &side) {
     src = k; neg = false; cst = false; side = 0;
     if (k < mbc && lo >= 0) {
@@ -327,9 +332,16 @@ __device__ __forceinline__ void frame_map(int k, int n, int mbc, int lo, int hi,
     }
 }
 __global__ void frame_kernel(double *q, double *dst, int nm, int I, int J, int mbc, long pitch, long plane, FrameBc f) {
-    const long ncell = (long)I * J;
+    // only the ghost cells are enumerated: 2*mbc whole rows (bottom, top), then 2*mbc cells of every other row.
+    // (1-D grids, J == 1, have no ghost rows: every cell of the single row is visited; interior ones map to themselves.)
+    const bool rows = J > 2 * mbc;
+    const long nfull = rows ? 2L * mbc * I : 0;
+    const long ncell = rows ? nfull + 2L * mbc * (J - 2 * mbc) : (long)I * J;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell; t += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(t % I), j = (int)(t / I);
+        int i, j;
+        if (!rows) { i = (int)(t % I); j = (int)(t / I); }
+        else if (t < nfull) { const int r = (int)(t / I); i = (int)(t % I); j = r < mbc ? r : J - 2 * mbc + r; }
+        else { const long u = t - nfull; const int c = (int)(u % (2 * mbc)); j = mbc + (int)(u / (2 * mbc)); i = c < mbc ? c : I - 2 * mbc + c; }
         if (i >= mbc && i < I - mbc && j >= mbc && j < J - mbc) continue;
         int si, sj, sdi, sdj;
         bool ni, nj, ci, cj;
@@ -371,8 +383,8 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
         // layers of qnew are copies of qold as well (step2ds.f / step1.f update interior cells of a copy)
         FrameBc f;
         for (int k = 0; k < 4; k++) { f.t[k] = -1; for (int m = 0; m < 8; m++) f.c[k][m] = 0.0; }
-        hipLaunchKernelGGL(frame_kernel, dim3(256), dim3(256), 0, stream, const_cast<double *>(qin), qout, s->cfg.meqn,
-                           s->I, s->J, s->cfg.mbc, s->pitch, s->plane, f);
+        hipLaunchKernelGGL(frame_kernel, dim3(frame_blocks(s)), dim3(256), 0, stream, const_cast<double *>(qin), qout,
+                           s->cfg.meqn, s->I, s->J, s->cfg.mbc, s->pitch, s->plane, f);
         HIP_TRY(hipGetLastError());
     }
     pcl_solver::Timed t{};
@@ -492,8 +504,8 @@ static int unsplit_frame(pcl_solver *s, hipStream_t stream, const int *bc = null
         f.t[k] = bc ? (bc[k] == PCL_BC_CUSTOM ? 100 : bc[k]) : -1;
         for (int m = 0; m < 8; m++) f.c[k][m] = (bc && bc[k] == PCL_BC_CUSTOM && cstate) ? cstate[k * PCL_MAX_RP_PARAMS + m] : 0.0;
     }
-    hipLaunchKernelGGL(frame_kernel, dim3(256), dim3(256), 0, stream, s->q, s->t1, s->cfg.meqn, s->I, s->J, s->cfg.mbc,
-                       s->pitch, s->plane, f);
+    hipLaunchKernelGGL(frame_kernel, dim3(frame_blocks(s)), dim3(256), 0, stream, s->q, s->t1, s->cfg.meqn, s->I, s->J,
+                       s->cfg.mbc, s->pitch, s->plane, f);
     HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
@@ -1235,6 +1247,17 @@ static int sharp_frame(pcl_solver *s, const int *bc, const double *cstate, hipSt
     std::string err;
     if (s->halo.active && s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err, stream))
         return fail(PCL_ECOMM, err);
+    if (s->cfg.ndim == 2) {       // all four sides in one launch (the index-remap composition of frame_kernel)
+        FrameBc f;
+        for (int k = 0; k < 4; k++) {
+            f.t[k] = bc[k] == PCL_BC_CUSTOM ? 100 : bc[k];
+            for (int m = 0; m < 8; m++) f.c[k][m] = (bc[k] == PCL_BC_CUSTOM && cstate) ? cstate[k * PCL_MAX_RP_PARAMS + m] : 0.0;
+        }
+        hipLaunchKernelGGL(frame_kernel, dim3(frame_blocks(s)), dim3(256), 0, stream, cur(s), (double *)nullptr, s->cfg.meqn,
+                           s->I, s->J, s->cfg.mbc, s->pitch, s->plane, f);
+        HIP_TRY(hipGetLastError());
+        return PCL_OK;
+    }
     for (int idim = 0; idim < s->cfg.ndim; idim++)
         for (int side = 0; side < 2; side++) {
             const int t = bc[2 * idim + side];
