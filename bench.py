@@ -42,13 +42,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_CELL_SWEEP = 2 * 5 * 8   # read + write of q (5 doubles) per directional pass
 
 
-def build(nx_global, ny_global, math, unsplit=False):
+def build(nx_global, ny_global, math, unsplit=False, with_src=False):
     import pyclaw_amd as pyclaw
     from apps import problems
     # dt_initial scaled with dx like the reference test (0.005 at dx=1/80) -> first CFL ~ 0.4-0.5
     dt0 = 0.005 * (2.0 / nx_global) / (2.0 / 160.0)
     claw = problems.shockbubble(pyclaw, mx=nx_global, my=ny_global, device_callbacks=True,
-                                with_src=False, dt_initial=dt0, run=False, math=math,
+                                with_src=with_src, dt_initial=dt0, run=False, math=math,
                                 dim_split=not unsplit, order_trans=2)
     return claw
 
@@ -496,6 +496,14 @@ def main():
                                               cells_total, bytes_launch, desc_dense)
             out["developed_state"] = state_object("developed", developed_state(build(nxg, nyg, "exact", False)), k2,
                                                   args.warmup, cells_total, bytes_launch, desc_dev)
+            # "source term off for the pure classic-step figure, on for the app figure": the same state
+            # with the app's axisymmetric source term (step_Euler_radial, device version) after every step
+            el5, ms5, nl5, fin5 = timed_run(build(nxg, nyg, "exact", False, with_src=True), k2, args.warmup)
+            out["app_figure"] = {"value": cells_total * k2 / el5 / 1e6, "unit": "Mcell*steps/s", "steps": k2,
+                                 "ms_per_step": el5 / k2 * 1e3, "math": "exact",
+                                 "what": "classic dim-split step + the app's radial source term (Godunov splitting, "
+                                         "EulerRadialSource on the device: one more read + write of q per step)",
+                                 "result_finite": fin5}
             if args.steps < 200:
                 # a K-step region of ~10 ms is thin: the same headline state for 1000 steps
                 el4, ms4, nl4, fin4 = timed_run(build(nxg, nyg, "exact", False), 1000, args.warmup)

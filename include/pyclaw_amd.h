@@ -253,6 +253,11 @@ int pcl_restore(pcl_solver *s);
  *       tangent plane, 4-stage RK, projection); aux components 14-16 = radial unit vector; no params. */
 #define PCL_SRC_SPHERE_CORIOLIS 2
 int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int nparams);
+/* Godunov-split source term (clawpack.py:156-159: step_src(dt) after an accepted hyperbolic step) applied by the LAST
+ * pass of the dimension-split 2-D step while it stores its results, instead of one more read + write of q by
+ * pcl_src: same arithmetic, same bits.  src_id = PCL_SRC_EULER_RADIAL with params {gamma1, ndim}, or 0 to switch it
+ * off.  A rejected step discards the pass' output with the rest (pcl_undo_step), as step() returns before the source. */
+int pcl_fuse_source(pcl_solver *s, int src_id, const double *params, int nparams);
 
 /* ---- SharpClaw (kind = PCL_KIND_SHARPCLAW) ----------------------------------------------------- */
 /* Which register the put/get/bc/strip/halo calls act on (default PCL_REG_Q): the RK stages get

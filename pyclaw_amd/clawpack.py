@@ -68,6 +68,7 @@ class ClawSolver(Solver):
         # no-FMA Fortran) or 'fast' (FMA + reciprocal-multiply divisions, rtol 1e-12)
         self._default_attr_values['math'] = 'exact'
         self.rp = None
+        self._src_fused = False
         self._cfl_out = None
         self._cfl_ptr = None
         super(ClawSolver, self).__init__(data)
@@ -87,12 +88,22 @@ class ClawSolver(Solver):
         self.step_hyperbolic(solution)
 
         if self.cfl.get_cached_max() >= self.cfl_max:
+            if self._src_fused and self.cfl.get_cached_max() == self.cfl_max:
+                # The reference returns here WITHOUT the source term while evolve_to_time accepts cfl == cfl_max
+                # (clawpack.py:153 vs solver.py:668): redo this step without the source fused into its last pass.
+                L = _lib.lib()
+                _lib.check(L.pcl_undo_step(self._h))
+                _lib.check(L.pcl_fuse_source(self._h, 0, None, 0))
+                try:
+                    self.step_hyperbolic(solution)
+                finally:
+                    _lib.check(L.pcl_fuse_source(self._h, 1, _lib.d(self.step_src.params), 2))
             return False
 
         if self.step_src is not None:
             if self.src_split == 2:
                 self._apply_src(state, self.dt / 2.0)
-            if self.src_split == 1:
+            if self.src_split == 1 and not self._src_fused:      # fused: the y pass applied it while storing
                 self._apply_src(state, self.dt)
         return True
 
@@ -225,6 +236,14 @@ class ClawSolver(Solver):
         self.allocate_bc_arrays(state)
         self._setup_halo(state)
         self._upload_aux(state)
+        # Godunov-split device source of the dimension-split 2-D Euler step: applied by the y pass while it stores its
+        # results (one read + write of q less per step; PCL_FUSE_SRC=0 keeps the separate source kernel)
+        import os
+        self._src_fused = False
+        if (isinstance(self.step_src, EulerRadialSource) and self.src_split == 1 and self.ndim == 2 and self.dim_split
+                and rp.id == 11 and os.environ.get("PCL_FUSE_SRC", "1") != "0"):
+            _lib.check(_lib.lib().pcl_fuse_source(self._h, 1, _lib.d(self.step_src.params), 2))
+            self._src_fused = True
 
     def teardown(self):
         super(ClawSolver, self).teardown()

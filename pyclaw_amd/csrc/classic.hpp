@@ -424,7 +424,9 @@ __device__ __forceinline__ int xcd_logical_block(int on) {
     return x * base + (x < rem ? x : rem) + k;
 }
 
-template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1>
+// SRC: the instantiation that applies the fused source term while storing (y pass of the Euler solver only; the
+// plain instantiation keeps its store loops untouched: a run-time switch there cost the memory-bound pass 4-5 %)
+template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool SRC = false>
 __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     using T = TileShape<IXY>;
     constexpr int MEQN = RP::MEQN;
@@ -655,12 +657,26 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     __syncthreads();
 
     // ---- cooperative store: owned interior cells + ghost cells along the sweep (copied through) ----
+    // the source term fused into the last pass of a dim-split step (SweepArgs.src_id): interior cells only
+    static_assert(!SRC || (IXY == 2 && !DIM1 && MEQN == 5 && RP::NAUX == 0), "fused source: y pass of the Euler solver");
+    auto interior = [&](int ga, int gb) {
+        return ga >= a.mbc && ga < a.mbc + m_along && gb >= a.mbc && gb < a.mbc + (IXY == 1 ? a.my : a.mx);
+    };
     auto put = [&](int al, int ac) {
         const int ga = a0 + al, gb = b0 + ac;
         if (ga < n_along && gb >= 0 && gb < n_across) {
             const long g = IXY == 1 ? (long)gb * a.pitch + ga : (long)ga * a.pitch + gb;
+            if constexpr (SRC) {
+                double v[MEQN];
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[T::at(m, al, ac)];
+                for (int m = 0; m < MEQN; m++) v[m] = tile[T::at(m, al, ac)];
+                if (interior(ga, gb)) euler_radial_source(v[0], v[1], v[2], v[3], a.aux[g], a.dt, a.src_p[0], a.src_p[1]);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = v[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = tile[T::at(m, al, ac)];
+            }
         }
     };
     if (IXY == 1 && full_tile) {
@@ -704,12 +720,30 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
             const bool inner = (ga >= a.mbc) && (ga < a.mbc + m_along);
             if (inner ? (al >= HALO && al < T::ALONG - HALO) : true) {
                 const long g = (long)ga * a.pitch + (b0 + ac);
+                if constexpr (SRC) {
+                    double vx[MEQN], vy[MEQN];
 #pragma unroll
-                for (int m = 0; m < MEQN; m++) {
-                    double2 v;
-                    v.x = tile[T::at(m, al, ac)];
-                    v.y = tile[T::at(m, al, ac + 1)];
-                    *reinterpret_cast<double2 *>(&a.qout[m * a.plane + g]) = v;
+                    for (int m = 0; m < MEQN; m++) {
+                        vx[m] = tile[T::at(m, al, ac)];
+                        vy[m] = tile[T::at(m, al, ac + 1)];
+                    }
+                    if (interior(ga, b0 + ac)) euler_radial_source(vx[0], vx[1], vx[2], vx[3], a.aux[g], a.dt, a.src_p[0], a.src_p[1]);
+                    if (interior(ga, b0 + ac + 1)) euler_radial_source(vy[0], vy[1], vy[2], vy[3], a.aux[g + 1], a.dt, a.src_p[0], a.src_p[1]);
+#pragma unroll
+                    for (int m = 0; m < MEQN; m++) {
+                        double2 v;
+                        v.x = vx[m];
+                        v.y = vy[m];
+                        *reinterpret_cast<double2 *>(&a.qout[m * a.plane + g]) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MEQN; m++) {
+                        double2 v;
+                        v.x = tile[T::at(m, al, ac)];
+                        v.y = tile[T::at(m, al, ac + 1)];
+                        *reinterpret_cast<double2 *>(&a.qout[m * a.plane + g]) = v;
+                    }
                 }
             }
         }

@@ -49,6 +49,18 @@ template <class RP, int IXY, bool DIM1> int launch(const SweepLaunch &l, std::st
                  : "solver.fwave = True needs an f-wave Riemann solver (elasticity_fwave_1d, psystem_fwave_2d)";
         return PCL_EINVAL;
     }
+    if (a.src_id != 0) {      // fused source term: its own instantiation (classic.hpp), Euler y pass without capa
+        if constexpr (IXY == 2 && !DIM1 && std::is_same<RP, Euler5>::value) {
+            if (a.src_id != 1 || a.mcapa > 0) { err = "fused source: Euler radial source, no capacity function"; return PCL_EINVAL; }
+            hipLaunchKernelGGL((sweep_kernel<RP, IXY, false, FW, DIM1, true>), grid, dim3(256), 0, l.stream, a,
+                               ntiles_across, ntiles_along);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? PCL_OK : hip_fail(err, "sweep launch", e);
+        } else {
+            err = "fused source: only the y pass of the Euler solver has it";
+            return PCL_EINVAL;
+        }
+    }
     if (a.mcapa > 0)
         hipLaunchKernelGGL((sweep_kernel<RP, IXY, true, FW, DIM1>), grid, dim3(256), 0, l.stream, a,
                            ntiles_across, ntiles_along);

@@ -55,6 +55,8 @@ struct pcl_solver {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_cfl = nullptr;
     double **undo_slot = nullptr;  // buffer that holds the pre-step state
+    int fused_src = 0;    // source term applied inside the last pass of the dim-split step (pcl_fuse_source)
+    double fused_src_p[2] = {0.0, 0.0};
     int timing = 0;       // 0 off, N >= 1: HIP events around the sweep launches of every N-th step (pcl_kernel_timing)
     long step_no = 0;     // hyperbolic steps / stages completed (read_cfl)
     int vbc_on = 0;       // next x pass evaluates these BCs while loading (pcl_bc_step)
@@ -179,27 +181,12 @@ __global__ void src_euler_radial(double *q, const double *aux, int mbc, int mx, 
     const int j = blockIdx.y;
     if (i >= mx || j >= my) return;
     const long g = (long)(j + mbc) * pitch + (i + mbc);
-    const double rad = aux[g];
-    const double q0 = q[g], q1 = q[plane + g], q2 = q[2 * plane + g], q3 = q[3 * plane + g];
-    const double dt2 = dt / 2.0;
-    double rho = q0;
-    double u = q1 / rho;
-    double v = q2 / rho;
-    double press = gamma1 * (q3 - 0.5 * rho * (u * u + v * v));
-    const double k2 = dt2 * ndm1 / rad;
-    const double s0 = q0 - k2 * q2;
-    const double s1 = q1 - k2 * rho * u * v;
-    const double s2 = q2 - k2 * rho * v * v;
-    const double s3 = q3 - k2 * v * (q3 + press);
-    rho = s0;
-    u = s1 / rho;
-    v = s2 / rho;
-    press = gamma1 * (s3 - 0.5 * rho * (u * u + v * v));
-    const double k1 = dt * ndm1 / rad;
-    q[g] = q0 - k1 * s2;
-    q[plane + g] = q1 - k1 * rho * u * v;
-    q[2 * plane + g] = q2 - k1 * rho * v * v;
-    q[3 * plane + g] = q3 - k1 * v * (s3 + press);
+    double q0 = q[g], q1 = q[plane + g], q2 = q[2 * plane + g], q3 = q[3 * plane + g];
+    pcl::euler_radial_source(q0, q1, q2, q3, aux[g], dt, gamma1, ndm1);
+    q[g] = q0;
+    q[plane + g] = q1;
+    q[2 * plane + g] = q2;
+    q[3 * plane + g] = q3;
 }
 
 // ---- sphere app: custom y boundary, shallow_4_Rossby_Haurwitz_wave.py:295-313 ---------------------------
@@ -271,6 +258,9 @@ SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, dou
     for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) a.par.v[k] = s->cfg.rp_params[k];
     a.cfl = s->cfl_dev;
     a.vbc_on = (ids == 1) ? s->vbc_on : 0;
+    // the fused source belongs to the LAST pass of the dimension-split 2-D step (pcl_fuse_source)
+    a.src_id = (ids == 2 && s->cfg.ndim == 2 && s->cfg.method[2] < 0) ? s->fused_src : 0;
+    a.src_p[0] = s->fused_src_p[0]; a.src_p[1] = s->fused_src_p[1];
     for (int k = 0; k < 4; k++) { a.vbc[k] = s->vbc[k]; for (int m = 0; m < 8; m++) a.vconst[k][m] = s->vconst[k][m]; }
     static const int ablate = [] { const char *e = getenv("PCL_TUNE_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
@@ -1210,6 +1200,20 @@ int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int npar
         return PCL_OK;
     }
     return fail(PCL_EINVAL, "unknown source id");
+}
+
+int pcl_fuse_source(pcl_solver *s, int src_id, const double *params, int nparams) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (src_id == 0) { s->fused_src = 0; return PCL_OK; }
+    if (src_id != PCL_SRC_EULER_RADIAL) return fail(PCL_EINVAL, "pcl_fuse_source: only the Euler radial source can be fused");
+    if (s->cfg.kind != PCL_KIND_CLASSIC || s->cfg.ndim != 2 || s->cfg.method[2] >= 0 || s->cfg.rp != PCL_RP_EULER5_2D ||
+        s->cfg.maux < 1 || s->cfg.method[5] != 0)
+        return fail(PCL_EINVAL, "pcl_fuse_source: dimension-split 2-D Euler solver with the radial coordinate in aux(1)");
+    if (!params || nparams < 2) return fail(PCL_EINVAL, "Euler radial source needs (gamma1, ndim)");
+    s->fused_src = src_id;
+    s->fused_src_p[0] = params[0];
+    s->fused_src_p[1] = params[1] - 1.0;
+    return PCL_OK;
 }
 
 int pcl_select(pcl_solver *s, int reg) {

@@ -12,6 +12,33 @@ struct RpParams {
     double v[8];
 };
 
+// Source term of the 2-D Euler equations with radial symmetry (test/euler/2d/shockbubble.py:59-94, the app's
+// step_Euler_radial): two-stage Runge-Kutta on one cell, in the operation order of the numpy callback.  Shared by the
+// stand-alone source kernel (pclaw.hip) and the y pass that applies it while storing its results (classic.hpp).
+__host__ __device__ inline void euler_radial_source(double &q0, double &q1, double &q2, double &q3, double rad, double dt,
+                                                    double gamma1, double ndm1) {
+    const double dt2 = dt / 2.0;
+    double rho = q0;
+    double u = q1 / rho;
+    double v = q2 / rho;
+    double press = gamma1 * (q3 - 0.5 * rho * (u * u + v * v));
+    const double k2 = dt2 * ndm1 / rad;
+    const double s0 = q0 - k2 * q2;
+    const double s1 = q1 - k2 * rho * u * v;
+    const double s2 = q2 - k2 * rho * v * v;
+    const double s3 = q3 - k2 * v * (q3 + press);
+    rho = s0;
+    u = s1 / rho;
+    v = s2 / rho;
+    press = gamma1 * (s3 - 0.5 * rho * (u * u + v * v));
+    const double k1 = dt * ndm1 / rad;
+    const double n0 = q0 - k1 * s2;
+    const double n1 = q1 - k1 * rho * u * v;
+    const double n2 = q2 - k1 * rho * v * v;
+    const double n3 = q3 - k1 * v * (s3 + press);
+    q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+}
+
 struct SweepArgs {
     const double *qin;
     double *qout;
@@ -55,6 +82,11 @@ struct SweepArgs {
     // unsplit algorithm (step2.f) only:
     int trans;        // method(3): 0 no transverse terms, 1 increment waves, 2 + correction waves
     double dtd_t;     // dt/d of the transverse direction
+    // (kept at the END of the block: the kernels' scalar loads of the fields above keep their offsets)
+    // source term applied by the LAST pass of a dimension-split step while it stores its results (Godunov splitting,
+    // clawpack.py:156-159): 0 none, 1 euler_radial_source(gamma1, ndim-1), aux plane 0 = radial coordinate
+    int src_id;
+    double src_p[2];
 };
 
 // unsplit 3-D (classic3.hpp): one direction's slices into 14 scratch plane sets, then the ordered combine

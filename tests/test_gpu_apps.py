@@ -271,3 +271,49 @@ def test_fast_mode_other_kernel_families(coracle):
     inner = (slice(None), slice(3, -3), slice(3, -3))
     assert abs(cfl.value - cfl_ref) < 1e-12 * cfl_ref
     assert np.max(np.abs(dq[inner] - ref[inner])) < 1e-11 * np.abs(ref[inner]).max()
+
+
+def test_fused_source_term_equals_separate_kernel(coracle, monkeypatch):
+    """The Godunov-split radial source applied inside the y pass (pcl_fuse_source) == the separate source kernel
+    (PCL_FUSE_SRC=0) == the oracle replay, bit for bit, with a rejected step on the way (dt_initial too large)."""
+    import pyclaw_amd as pyclaw
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("PCL_FUSE_SRC", fuse)
+        claw = problems.shockbubble(pyclaw, tfinal=0.05, device_callbacks=True, dt_initial=0.02, run=False)
+        claw.run()
+        assert claw.solver._src_fused == (fuse == "1")
+        res[fuse] = (claw.frames[claw.nout].state.q.copy(), dict(claw.solver.status))
+    assert np.array_equal(res["1"][0], res["0"][0]) and res["1"][1] == res["0"][1]
+    p = D.shockbubble_problem(dt_initial=0.02)
+    st = D.run(p, coracle, 0.05, 1)[-1]
+    assert p.nrejected >= 1 and res["1"][1]["numsteps"] == st["numsteps"]
+    assert np.array_equal(res["1"][0], p.q)
+
+
+def test_fused_source_when_cfl_equals_cfl_max(monkeypatch):
+    """clawpack.py:153 returns without the source term when cfl >= cfl_max, solver.py:668 accepts cfl <= cfl_max: at
+    equality the reference keeps the hyperbolic step WITHOUT its source.  With the source fused into the y pass that
+    step is redone unfused: same result as the separate-kernel path."""
+    import pyclaw_amd as pyclaw
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("PCL_FUSE_SRC", fuse)
+        probe = problems.shockbubble(pyclaw, tfinal=1.0, device_callbacks=True, run=False)
+        probe.solver.setup(probe.solution)
+        probe.solver.dt = probe.solver.dt_initial
+        probe.solver.evolve_to_time(probe.solution)              # one step: its Courant number
+        c1 = probe.solver.cfl.get_cached_max()
+        probe.solver.teardown()
+        claw = problems.shockbubble(pyclaw, tfinal=1.0, device_callbacks=True, run=False)
+        claw.solver.cfl_max = c1                                  # the first step lands exactly on cfl_max
+        claw.solver.cfl_desired = 0.9 * c1
+        claw.solver.setup(claw.solution)
+        claw.solver.dt = claw.solver.dt_initial
+        for _ in range(3):
+            claw.solver.evolve_to_time(claw.solution)
+        claw.solver._pull(claw.solution.state) if hasattr(claw.solver, "_pull") else None
+        out[fuse] = (claw.solution.state.q.copy(), claw.solution.t, c1)
+        claw.solver.teardown()
+    assert out["1"][2] == out["0"][2] and out["1"][1] == out["0"][1]
+    assert np.array_equal(out["1"][0], out["0"][0])
