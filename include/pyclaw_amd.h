@@ -254,7 +254,7 @@ int pcl_restore(pcl_solver *s);
 #define PCL_SRC_SPHERE_CORIOLIS 2
 int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int nparams);
 /* Godunov-split source term (clawpack.py:156-159: step_src(dt) after an accepted hyperbolic step) applied by the LAST
- * pass of the dimension-split 2-D step while it stores its results, instead of one more read + write of q by
+ * pass of the 2-D step (y pass of step2ds, y phase of step2) while it stores its results, instead of one more read + write of q by
  * pcl_src: same arithmetic, same bits.  src_id = PCL_SRC_EULER_RADIAL with params {gamma1, ndim}, or 0 to switch it
  * off.  A rejected step discards the pass' output with the rest (pcl_undo_step), as step() returns before the source. */
 int pcl_fuse_source(pcl_solver *s, int src_id, const double *params, int nparams);

@@ -236,12 +236,12 @@ class ClawSolver(Solver):
         self.allocate_bc_arrays(state)
         self._setup_halo(state)
         self._upload_aux(state)
-        # Godunov-split device source of the dimension-split 2-D Euler step: applied by the y pass while it stores its
+        # Godunov-split device source of the 2-D Euler step: applied by the y pass / y phase while it stores its
         # results (one read + write of q less per step; PCL_FUSE_SRC=0 keeps the separate source kernel)
         import os
         self._src_fused = False
-        if (isinstance(self.step_src, EulerRadialSource) and self.src_split == 1 and self.ndim == 2 and self.dim_split
-                and rp.id == 11 and os.environ.get("PCL_FUSE_SRC", "1") != "0"):
+        if (isinstance(self.step_src, EulerRadialSource) and self.src_split == 1 and self.ndim == 2
+                and rp.id == 11 and state.mcapa < 0 and os.environ.get("PCL_FUSE_SRC", "1") != "0"):
             _lib.check(_lib.lib().pcl_fuse_source(self._h, 1, _lib.d(self.step_src.params), 2))
             self._src_fused = True
 

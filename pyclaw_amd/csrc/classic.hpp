@@ -855,7 +855,8 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_x_kernel(SweepArgs a, i
 }
 
 // y phase: qx = result of the x phase (read and overwritten cell by cell), a.qin = qold
-template <class RP, bool FWAVE, int U_WAVES, bool CAPA = false>
+// SRC: the fused Godunov-split source term, as in sweep_kernel (own instantiation, Euler solver without capa)
+template <class RP, bool FWAVE, int U_WAVES, bool CAPA = false, bool SRC = false>
 __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, int ntiles_i, const double *qx) {
     constexpr int MEQN = RP::MEQN;
     constexpr int U_OUT = U_WAVES - 2;
@@ -999,12 +1000,26 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
                         gj >= a.mbc && gj < a.mbc + a.my;
         if (ok) {
             const long g = (long)gj * a.pitch + gi;
+            if constexpr (SRC) {
+                static_assert(MEQN == 5 && !CAPA, "fused source: Euler solver without a capacity function");
+                double w[MEQN];
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) {
-                double v = qx[m * a.plane + g] + gp[c - 1][m][r];
-                v = v + tile[m][r][c];
-                v = v - gm[c + 1][m][r];
-                a.qout[m * a.plane + g] = v;
+                for (int m = 0; m < MEQN; m++) {
+                    double v = qx[m * a.plane + g] + gp[c - 1][m][r];
+                    v = v + tile[m][r][c];
+                    w[m] = v - gm[c + 1][m][r];
+                }
+                euler_radial_source(w[0], w[1], w[2], w[3], a.aux[g], a.dt, a.src_p[0], a.src_p[1]);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = w[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) {
+                    double v = qx[m * a.plane + g] + gp[c - 1][m][r];
+                    v = v + tile[m][r][c];
+                    v = v - gm[c + 1][m][r];
+                    a.qout[m * a.plane + g] = v;
+                }
             }
         }
     }

@@ -210,7 +210,16 @@ template <class RP, int UX, int UY> int launch_unsplit_u(const SweepLaunch &l, c
     } else {
         const int nti = (a.mx + (UY - 2) - 1) / (UY - 2);
         const int ntj = (a.my + STRIP - 1) / STRIP;
-        if (a.mcapa > 0)
+        if (a.src_id != 0) {       // fused source term: Euler solver without a capacity function
+            if constexpr (std::is_same<RP, Euler5>::value) {
+                if (a.src_id != 1 || a.mcapa > 0) { err = "fused source: Euler radial source, no capacity function"; return PCL_EINVAL; }
+                hipLaunchKernelGGL((unsplit_y_kernel<RP, false, UY, false, true>), dim3((unsigned)nti * ntj),
+                                   dim3(UY * WAVE), 0, l.stream, a, nti, qx);
+            } else {
+                err = "fused source: only the Euler solver has it";
+                return PCL_EINVAL;
+            }
+        } else if (a.mcapa > 0)
             hipLaunchKernelGGL((unsplit_y_kernel<RP, IsFwave<RP>::value, UY, true>), dim3((unsigned)nti * ntj),
                                dim3(UY * WAVE), 0, l.stream, a, nti, qx);
         else

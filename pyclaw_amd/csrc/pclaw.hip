@@ -259,7 +259,7 @@ SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, dou
     a.cfl = s->cfl_dev;
     a.vbc_on = (ids == 1) ? s->vbc_on : 0;
     // the fused source belongs to the LAST pass of the dimension-split 2-D step (pcl_fuse_source)
-    a.src_id = (ids == 2 && s->cfg.ndim == 2 && s->cfg.method[2] < 0) ? s->fused_src : 0;
+    a.src_id = (ids == 2 && s->cfg.ndim == 2) ? s->fused_src : 0;      // y pass (dim-split) / y phase (unsplit)
     a.src_p[0] = s->fused_src_p[0]; a.src_p[1] = s->fused_src_p[1];
     for (int k = 0; k < 4; k++) { a.vbc[k] = s->vbc[k]; for (int m = 0; m < 8; m++) a.vconst[k][m] = s->vconst[k][m]; }
     static const int ablate = [] { const char *e = getenv("PCL_TUNE_ABLATE"); return e ? atoi(e) : 0; }();
@@ -1206,9 +1206,9 @@ int pcl_fuse_source(pcl_solver *s, int src_id, const double *params, int nparams
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (src_id == 0) { s->fused_src = 0; return PCL_OK; }
     if (src_id != PCL_SRC_EULER_RADIAL) return fail(PCL_EINVAL, "pcl_fuse_source: only the Euler radial source can be fused");
-    if (s->cfg.kind != PCL_KIND_CLASSIC || s->cfg.ndim != 2 || s->cfg.method[2] >= 0 || s->cfg.rp != PCL_RP_EULER5_2D ||
-        s->cfg.maux < 1 || s->cfg.method[5] != 0)
-        return fail(PCL_EINVAL, "pcl_fuse_source: dimension-split 2-D Euler solver with the radial coordinate in aux(1)");
+    if (s->cfg.kind != PCL_KIND_CLASSIC || s->cfg.ndim != 2 || s->cfg.rp != PCL_RP_EULER5_2D || s->cfg.maux < 1 ||
+        s->cfg.method[5] != 0)
+        return fail(PCL_EINVAL, "pcl_fuse_source: 2-D Euler solver without a capacity function, radial coordinate in aux(1)");
     if (!params || nparams < 2) return fail(PCL_EINVAL, "Euler radial source needs (gamma1, ndim)");
     s->fused_src = src_id;
     s->fused_src_p[0] = params[0];

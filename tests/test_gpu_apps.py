@@ -273,19 +273,21 @@ def test_fast_mode_other_kernel_families(coracle):
     assert np.max(np.abs(dq[inner] - ref[inner])) < 1e-11 * np.abs(ref[inner]).max()
 
 
-def test_fused_source_term_equals_separate_kernel(coracle, monkeypatch):
-    """The Godunov-split radial source applied inside the y pass (pcl_fuse_source) == the separate source kernel
-    (PCL_FUSE_SRC=0) == the oracle replay, bit for bit, with a rejected step on the way (dt_initial too large)."""
+@pytest.mark.parametrize("dim_split", [True, False])
+def test_fused_source_term_equals_separate_kernel(coracle, monkeypatch, dim_split):
+    """The Godunov-split radial source applied inside the y pass / y phase (pcl_fuse_source) == the separate source
+    kernel (PCL_FUSE_SRC=0) == the oracle replay, bit for bit, with a rejected step on the way (dt_initial too large)."""
     import pyclaw_amd as pyclaw
     res = {}
     for fuse in ("1", "0"):
         monkeypatch.setenv("PCL_FUSE_SRC", fuse)
-        claw = problems.shockbubble(pyclaw, tfinal=0.05, device_callbacks=True, dt_initial=0.02, run=False)
+        claw = problems.shockbubble(pyclaw, tfinal=0.05, device_callbacks=True, dt_initial=0.02, run=False,
+                                    dim_split=dim_split)
         claw.run()
         assert claw.solver._src_fused == (fuse == "1")
         res[fuse] = (claw.frames[claw.nout].state.q.copy(), dict(claw.solver.status))
     assert np.array_equal(res["1"][0], res["0"][0]) and res["1"][1] == res["0"][1]
-    p = D.shockbubble_problem(dt_initial=0.02)
+    p = D.shockbubble_problem(dt_initial=0.02, dim_split=dim_split)
     st = D.run(p, coracle, 0.05, 1)[-1]
     assert p.nrejected >= 1 and res["1"][1]["numsteps"] == st["numsteps"]
     assert np.array_equal(res["1"][0], p.q)
