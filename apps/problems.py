@@ -75,10 +75,30 @@ def euler_rad_src(solver, state, dt):
     q[3, :, :] = q[3, :, :] - dt * (ndim - 1) / rad * v * (qstar[3, :, :] + press)
 
 
+def dq_euler_radial(solver, state, dt):
+    """apps/euler/2d/shockbubble/shockbubble.py:95-122 (dq_Euler_radial): the SharpClaw form of the source."""
+    ndim = 2
+    q = state.q
+    rad = state.aux[0, :, :]
+    rho = q[0, :, :]
+    u = q[1, :, :] / rho
+    v = q[2, :, :] / rho
+    press = gamma1 * (q[3, :, :] - 0.5 * rho * (u ** 2 + v ** 2))
+    dq = np.empty(q.shape)
+    dq[0, :, :] = -dt * (ndim - 1) / rad * q[2, :, :]
+    dq[1, :, :] = -dt * (ndim - 1) / rad * rho * u * v
+    dq[2, :, :] = -dt * (ndim - 1) / rad * rho * v * v
+    dq[3, :, :] = -dt * (ndim - 1) / rad * v * (q[3, :, :] + press)
+    dq[4, :, :] = 0
+    return dq
+
+
 def shockbubble(pyclaw, mx=160, my=40, tfinal=0.2, device_callbacks=False, with_src=True,
-                dim_split=True, order_trans=2, dt_initial=0.005, nout=1, run=True, math='exact'):
-    """test/euler/2d/shockbubble.py:97-166.  device_callbacks=True swaps the Python
-    custom-BC / source callbacks for the built-in device versions (same arithmetic)."""
+                dim_split=True, order_trans=2, dt_initial=0.005, nout=1, run=True, math='exact',
+                solver_type='classic', time_integrator='SSP104'):
+    """test/euler/2d/shockbubble.py:97-166; solver_type='sharpclaw' as in apps/euler/2d/shockbubble/shockbubble.py:173-176
+    (dq_src in place of step_src, WENO5).  device_callbacks=True swaps the Python custom-BC / source callbacks for the
+    built-in device versions (same arithmetic)."""
     x = pyclaw.Dimension('x', 0.0, 2.0, mx)
     y = pyclaw.Dimension('y', 0.0, 0.5, my)
     grid = pyclaw.Grid([x, y])
@@ -91,24 +111,34 @@ def shockbubble(pyclaw, mx=160, my=40, tfinal=0.2, device_callbacks=False, with_
     sb_auxinit(state)
     initial_solution = pyclaw.Solution(state)
 
-    solver = pyclaw.ClawSolver2D()
+    sharp = solver_type == 'sharpclaw'
+    solver = pyclaw.SharpClawSolver2D() if sharp else pyclaw.ClawSolver2D()
     solver.math = math
     solver.rp = pyclaw.riemann.rp_euler_5wave_2d
-    solver.cfl_max = 0.5
-    solver.cfl_desired = 0.45
     solver.mwaves = 5
-    solver.limiters = [4, 4, 4, 4, 2]
     solver.dt_initial = dt_initial
-    solver.dim_split = dim_split
-    solver.order_trans = order_trans
+    if sharp:
+        solver.weno_order = 5
+        solver.lim_type = 2
+        solver.time_integrator = time_integrator
+    else:
+        solver.cfl_max = 0.5
+        solver.cfl_desired = 0.45
+        solver.limiters = [4, 4, 4, 4, 2]
+        solver.dim_split = dim_split
+        solver.order_trans = order_trans
+        solver.src_split = 1
     if device_callbacks:
         rinf, vinf, einf = shock_state()
         solver.user_bc_lower = pyclaw.ConstantStateBC([rinf, rinf * vinf, 0., einf, 0.])
-        solver.step_src = pyclaw.EulerRadialSource(gamma1, 2) if with_src else None
+        src = (pyclaw.EulerRadialDqSource if sharp else pyclaw.EulerRadialSource)(gamma1, 2)
     else:
         solver.user_bc_lower = shockbc
-        solver.step_src = euler_rad_src if with_src else None
-    solver.src_split = 1
+        src = dq_euler_radial if sharp else euler_rad_src
+    if sharp:
+        solver.dq_src = src if with_src else None
+    else:
+        solver.step_src = src if with_src else None
     solver.bc_lower[0] = pyclaw.BC.custom
     solver.bc_upper[0] = pyclaw.BC.outflow
     solver.bc_lower[1] = pyclaw.BC.reflecting

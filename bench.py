@@ -104,8 +104,9 @@ def build_sphere(nx, ny, math, solver_type):
     return claw
 
 
-def build_sharp(nx, ny, math):
-    """SharpClaw (WENO5 + SSP104, 10 right-hand sides per step) on the shock-bubble problem."""
+def build_sharp(nx, ny, math, dq_src=False):
+    """SharpClaw (WENO5 + SSP104, 10 right-hand sides per step) on the shock-bubble problem; dq_src: the app's
+    dq_Euler_radial (apps/euler/2d/shockbubble/shockbubble.py:173-176) as its device twin, fused in the last pass."""
     import pyclaw_amd as pyclaw
     from apps import problems
     x = pyclaw.Dimension('x', 0.0, 2.0, nx)
@@ -127,6 +128,8 @@ def build_sharp(nx, ny, math):
     solver.aux_bc_lower = [pyclaw.BC.outflow] * 2
     solver.aux_bc_upper = [pyclaw.BC.outflow] * 2
     solver.dt_initial = 0.4 * (2.0 / nx)
+    if dq_src:
+        solver.dq_src = pyclaw.EulerRadialDqSource(problems.gamma1, 2)
     claw = pyclaw.Controller()
     claw.solution = pyclaw.Solution(state)
     claw.solver = solver
@@ -333,6 +336,8 @@ def main():
                     help="sphere: apps/shallow-sphere (Rossby-Haurwitz wave, 16 aux planes, capacity function) on an "
                          "nx x nx/2 grid, default 2048x1024 = BASELINE configs[4]'s grid; --solver classic is the "
                          "reference app (unsplit step2qcor + Coriolis source), --solver sharpclaw the configs[4] variant")
+    ap.add_argument("--dq-src", dest="dq_src", action="store_true",
+                    help="--solver sharpclaw: with the app's radial source (dq_src) evaluated inside the last pass")
     ap.add_argument("--ndim", type=int, default=2, choices=[2, 3],
                     help="3: 3-D dim-split acoustics on an nx^3 grid (single GPU; not the headline)")
     args = ap.parse_args()
@@ -374,7 +379,7 @@ def main():
         # interior tiles of its x pass (pcl_sharp_bc_stage)
         dims = parallel.proc_grid([args.nx, args.ny], size) if size > 1 else [1, 1]
         nxg, nyg = args.nx * dims[0], args.ny * dims[1]
-        claw = build_sharp(nxg, nyg, args.math)
+        claw = build_sharp(nxg, nyg, args.math, args.dq_src)
     elif args.glob is not None:
         # strong scaling: the global grid is fixed and cut into px x py blocks (PETSc DMDA rule, parallel.py)
         scaling = "strong"
@@ -468,7 +473,9 @@ def main():
         if args.solver == "sharpclaw":
             out["metric"] = "Mcell*steps/s, 2-D Euler SharpClaw WENO5 + SSP104 step (10 right-hand sides per step)"
             out["config"]["workload"] = ("apps/euler 2D shock-bubble, %dx%d cells, SharpClaw lim_type=2 (WENO5), "
-                                         "SSP104, source off" % (args.nx, args.ny))
+                                         "SSP104, %s" % (args.nx, args.ny,
+                                                         "dq_src = dq_Euler_radial added by the last pass of every stage"
+                                                         if args.dq_src else "source off"))
         if args.app == "sphere":
             out["metric"] = ("Mcell*steps/s, shallow water on the sphere, %s"
                              % ("SharpClaw WENO5 + SSP104 step (10 right-hand sides per step)"

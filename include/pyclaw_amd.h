@@ -263,6 +263,12 @@ int pcl_fuse_source(pcl_solver *s, int src_id, const double *params, int nparams
 /* Which register the put/get/bc/strip/halo calls act on (default PCL_REG_Q): the RK stages get
  * their ghost cells filled exactly like q (apply_q_bcs(stage), sharpclaw.py:546). */
 int pcl_select(pcl_solver *s, int reg);
+/* deltaq += dq_src(stage) of sharpclaw.py:232-235 evaluated by the LAST pass of every stage while it stores deltaq (or
+ * its RK combination), for the built-in twin of the shock-bubble app's dq_Euler_radial
+ * (apps/euler/2d/shockbubble/shockbubble.py:95-122): src_id = PCL_SRC_EULER_RADIAL with params {gamma1, ndim}; 0 switches
+ * it off.  Needs euler_5wave_2d, lim_type 2 with mbc 3 (WENO5), no capacity function, aux(1) = radial coordinate. */
+int pcl_sharp_fuse_dq_src(pcl_solver *s, int src_id, const double *params, int nparams);
+
 /* sharpclaw1.flux1 / sharpclaw2.flux2 (sharpclaw.py:385,558; flux1.f90, flux2.f90): dq register :=
  * dt * dq/dt of the selected register (ghost cells must be filled); *cfl = max Courant number (global
  * after pcl_comm_init). */

@@ -87,6 +87,7 @@ class Problem:
         self.src_split = 1
         self.fwave = False
         self.step_src = None          # f(problem, q_interior_view, aux, dt)
+        self.dq_src = None            # SharpClaw: f(problem, q_stage_interior, aux, dt) -> increment (sharpclaw.py:232-235)
         self.cfl_max = 1.0
         self.cfl_desired = 0.9
         self.dt_initial = 0.1
@@ -292,7 +293,10 @@ def sharp_dq(p, backend, q, t):
     p.cfl = cfl                                            # CFL.update_global_max overwrites
     if cfl > p.cfl_max:
         raise CFLError()
-    return dq[inner]
+    deltaq = dq[inner]
+    if p.dq_src is not None:
+        deltaq = deltaq + p.dq_src(p, q, p.aux, p.dt)      # deltaq += dq_src(solver, state, dt)
+    return deltaq
 
 
 def sharp_step(p, backend):
@@ -396,14 +400,37 @@ def shockbubble_problem(mx=160, my=40, with_src=True, dim_split=True, order_tran
         q[2, :, :] = q[2, :, :] - dt * (ndim - 1) / rad * rho * v * v
         q[3, :, :] = q[3, :, :] - dt * (ndim - 1) / rad * v * (qstar[3, :, :] + press)
 
-    return Problem(
+    def dq_euler_radial(p, q, aux, dt):
+        """apps/euler/2d/shockbubble/shockbubble.py:95-122 (dq_Euler_radial)"""
+        ndim = 2
+        rad = aux[0, :, :]
+        rho = q[0, :, :]
+        u = q[1, :, :] / rho
+        v = q[2, :, :] / rho
+        press = gamma1 * (q[3, :, :] - 0.5 * rho * (u ** 2 + v ** 2))
+        dq = np.empty(q.shape)
+        dq[0, :, :] = -dt * (ndim - 1) / rad * q[2, :, :]
+        dq[1, :, :] = -dt * (ndim - 1) / rad * rho * u * v
+        dq[2, :, :] = -dt * (ndim - 1) / rad * rho * v * v
+        dq[3, :, :] = -dt * (ndim - 1) / rad * v * (q[3, :, :] + press)
+        dq[4, :, :] = 0
+        return dq
+
+    if kw.get("solver_type") == "sharpclaw":
+        kw.setdefault("dq_src", dq_euler_radial if with_src else None)
+        with_src = False                                   # the app sets dq_src instead of step_src (shockbubble.py:173-176)
+        kw.setdefault("cfl_max", 2.5)                      # the SharpClawSolver defaults (sharpclaw.py:143-144)
+        kw.setdefault("cfl_desired", 2.45)
+    args = dict(
         q=q, aux=aux, d=(2.0 / float(mx), 0.5 / float(my)),
         rp=RP_EULER5_2D, rp_params=[gamma, gamma1], mwaves=5, limiters=[4, 4, 4, 4, 2],
         cfl_max=0.5, cfl_desired=0.45, dt_initial=dt_initial,
         bc_lower=[CUSTOM, REFLECTING], bc_upper=[OUTFLOW, OUTFLOW], user_bc_lower=shockbc,
         aux_bc_lower=[OUTFLOW, OUTFLOW], aux_bc_upper=[OUTFLOW, OUTFLOW],
         step_src=euler_rad_src if with_src else None, src_split=1,
-        dim_split=dim_split, order_trans=order_trans, **kw)
+        dim_split=dim_split, order_trans=order_trans)
+    args.update(kw)
+    return Problem(**args)
 
 
 def acoustics2d_problem(mx=100, my=100, dim_split=True, order_trans=2, bcs=None, **kw):

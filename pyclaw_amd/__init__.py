@@ -11,10 +11,10 @@ from .cfl import CFL
 from .clawpack import ClawSolver1D, ClawSolver2D, ClawSolver3D, DeviceSource, EulerRadialSource, SphereCoriolisSource
 from .controller import Controller
 from .grid import Dimension, Grid
-from .sharpclaw import SharpClawSolver1D, SharpClawSolver2D
+from .sharpclaw import SharpClawSolver1D, SharpClawSolver2D, DeviceDqSource, EulerRadialDqSource
 from .solution import Solution
 from .solver import BC, ConstantStateBC, DeviceBC, SphereMirrorBC
 from .state import State
 
 __all__ = ['limiters', 'riemann', 'CFL', 'ClawSolver1D', 'ClawSolver2D', 'ClawSolver3D', 'DeviceSource', 'EulerRadialSource', 'SphereCoriolisSource', 'SphereMirrorBC',
-           'Controller', 'SharpClawSolver1D', 'SharpClawSolver2D', 'Dimension', 'Grid', 'Solution', 'BC', 'ConstantStateBC', 'DeviceBC', 'State']
+           'Controller', 'SharpClawSolver1D', 'SharpClawSolver2D', 'DeviceDqSource', 'EulerRadialDqSource', 'Dimension', 'Grid', 'Solution', 'BC', 'ConstantStateBC', 'DeviceBC', 'State']

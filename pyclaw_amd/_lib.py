@@ -86,6 +86,7 @@ PROTOTYPES = {
     "pcl_src": (C.c_int, [C.c_void_p, C.c_int, C.c_double, dp, C.c_int]),
     "pcl_fuse_source": (C.c_int, [C.c_void_p, C.c_int, dp, C.c_int]),
     "pcl_select": (C.c_int, [C.c_void_p, C.c_int]),
+    "pcl_sharp_fuse_dq_src": (C.c_int, [C.c_void_p, C.c_int, dp, C.c_int]),
     "pcl_sharp_dq": (C.c_int, [C.c_void_p, C.c_double, dp]),
     "pcl_sharp_stage": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                   C.c_double, C.c_double, dp]),

@@ -291,6 +291,19 @@ template <class RP, int IXY, int K> int launch_sharp_k(const SweepLaunch &l, std
 #define PCL_SHARP_LAUNCH(CAPA_, LIM_)                                                                  \
     hipLaunchKernelGGL((sharp_kernel<RP, IXY, CAPA_, LIM_, K>), grid, dim3(256), 0, l.stream, a, ntiles_across, \
                        ntiles_along)
+    if (a.src_id != 0) {
+        // deltaq += dq_src inside the last pass: built for the shock-bubble configuration only
+        if constexpr (std::is_same<RP, Euler5>::value && IXY == 2 && K == 3) {
+            if (a.src_id != 1 || capa || l.lim_type != 2) { err = "SharpClaw: the fused dq source needs euler_5wave_2d, WENO5 (lim_type 2), no capacity function"; return PCL_EINVAL; }
+            hipLaunchKernelGGL((sharp_kernel<RP, IXY, false, 2, K, true>), grid, dim3(256), 0, l.stream, a, ntiles_across,
+                               ntiles_along);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? PCL_OK : hip_fail(err, "sharp launch", e);
+        } else {
+            err = "SharpClaw: the fused dq source needs euler_5wave_2d, WENO5 (lim_type 2), no capacity function";
+            return PCL_EINVAL;
+        }
+    }
     if constexpr (K > 3) {
         if (l.lim_type != 2) { err = "SharpClaw: weno_order > 5 needs lim_type 2"; return PCL_EINVAL; }
         if (capa) PCL_SHARP_LAUNCH(true, 2); else PCL_SHARP_LAUNCH(false, 2);

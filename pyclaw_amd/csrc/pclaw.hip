@@ -1216,6 +1216,22 @@ int pcl_fuse_source(pcl_solver *s, int src_id, const double *params, int nparams
     return PCL_OK;
 }
 
+int pcl_sharp_fuse_dq_src(pcl_solver *s, int src_id, const double *params, int nparams) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (s->cfg.kind != PCL_KIND_SHARPCLAW) return fail(PCL_EINVAL, "pcl_sharp_fuse_dq_src: not a SharpClaw solver");
+    if (src_id == 0) { s->fused_src = 0; return PCL_OK; }
+    if (src_id != PCL_SRC_EULER_RADIAL) return fail(PCL_EINVAL, "pcl_sharp_fuse_dq_src: only the Euler radial source can be fused");
+    if (s->cfg.ndim != 2 || s->cfg.rp != PCL_RP_EULER5_2D || s->cfg.maux < 1 || s->cfg.method[5] != 0 ||
+        s->cfg.mbc != 3 || s->cfg.lim_type != 2)
+        return fail(PCL_EINVAL, "pcl_sharp_fuse_dq_src: 2-D Euler solver, WENO5 (lim_type 2, mbc 3), no capacity function, "
+                                "radial coordinate in aux(1)");
+    if (!params || nparams < 2) return fail(PCL_EINVAL, "Euler radial source needs (gamma1, ndim)");
+    s->fused_src = src_id;
+    s->fused_src_p[0] = params[0];
+    s->fused_src_p[1] = params[1] - 1.0;
+    return PCL_OK;
+}
+
 int pcl_select(pcl_solver *s, int reg) {
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (reg == 0) { s->sel = 0; return PCL_OK; }

@@ -204,7 +204,7 @@ template <int IXY, int TA = T_ACROSS_S> __device__ __forceinline__ int stile_at(
 #ifndef PCL_SHARP_OCC
 #define PCL_SHARP_OCC 4     // workgroups per CU the register budget is sized for (A/B: build with -DPCL_SHARP_OCC=3)
 #endif
-template <class RP, int IXY, bool CAPA, int LIM, int K = 3>
+template <class RP, int IXY, bool CAPA, int LIM, int K = 3, bool SRC = false>
 __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     constexpr int SHALO = K, SSTRIP = sstrip(K);      // a.mbc == K (checked by the launcher)
@@ -345,11 +345,23 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
         const bool inner_ac = gb >= 0 && gb < n_across && (one_d || ((gb >= a.mbc) && (gb < a.mbc + m_across)));
         if (inner_al && inner_ac) {
             const long g = IXY == 1 ? (long)gb * a.pitch + ga : (long)ga * a.pitch + gb;
+            // SRC: deltaq += dq_src(stage) (sharpclaw.py:232-235) with the device twin of the app's dq_Euler_radial,
+            // evaluated on the stage's own q; a separate instantiation, the others carry none of this
+            double dsrc[MEQN];
+            if constexpr (SRC) {
+                static_assert(IXY == 2 && MEQN >= 4, "the fused dq source belongs to the last pass of the 2-D Euler stage");
+                double d4[4];
+                euler_radial_dq(a.qin[g], a.qin[a.plane + g], a.qin[2 * a.plane + g], a.qin[3 * a.plane + g], a.aux[g],
+                                a.dt, a.src_p[0], a.src_p[1], d4);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) dsrc[m] = m < 4 ? d4[m] : 0.0;
+            }
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
                 const long at = m * a.plane + g;
                 const double v = tile[stile_at<IXY, TA>(m, al, ac)];
-                const double dq = IXY == 1 ? v : a.qout[at] + v;  // dq = (0 + dq1d_x) + dq1d_y
+                double dq = IXY == 1 ? v : a.qout[at] + v;  // dq = (0 + dq1d_x) + dq1d_y
+                if constexpr (SRC) dq = dq + dsrc[m];
                 // last pass of a stage: the RK combination of sharpclaw.py:168-206 (same expressions as rk_kernel).
                 // Branch-free on purpose: with a scalar branch per op the ROCm 7.2 backend left the store base
                 // of the op-5 path undefined in the 1-D instantiation (memory fault at address 0).
@@ -364,7 +376,18 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
                 double r = dq;
                 if (a.rk_op != 0) {
                     const double av = a.rk_a[at], bv = a.rk_b[at];
-                    const double r1 = av + by_ca.div(dq);
+                    double quo = by_ca.div(dq);
+#if !PCL_FAST
+                    // an increment deep in the underflow range (tails of a source term, products of tiny momenta): the
+                    // shortcut's residual is no longer exact there, take the IEEE quotient (rare, divergent branch)
+                    // (the empty volatile asm keeps it a branch: if-converted, the division would run for every cell
+                    // and cost the pass 4 %)
+                    if (a.rk_op == 1 && __builtin_fabs(dq) < 0x1p-900 && dq != 0.0) {
+                        asm volatile("");
+                        quo = dq / a.rk_ca;
+                    }
+#endif
+                    const double r1 = av + quo;
                     const double r2 = a.rk_ca * av + a.rk_cb * (bv + dq);
                     const double r5 = av + a.rk_cb * bv + a.rk_cc * dq;
                     r = a.rk_op == 1 ? r1 : (a.rk_op == 2 ? r2 : r5);

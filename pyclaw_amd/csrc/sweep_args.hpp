@@ -39,6 +39,22 @@ __host__ __device__ inline void euler_radial_source(double &q0, double &q1, doub
     q0 = n0; q1 = n1; q2 = n2; q3 = n3;
 }
 
+// SharpClaw form of the same source (apps/euler/2d/shockbubble/shockbubble.py:95-122, dq_Euler_radial): the increment
+// dt * psi(q) of one cell, in the operation order of the numpy callback (-dt*(ndim-1)/rad is one array, then the
+// products left to right); the energy-equation tracer component gets 0.
+__host__ __device__ inline void euler_radial_dq(double q0, double q1, double q2, double q3, double rad, double dt,
+                                                double gamma1, double ndm1, double (&d)[4]) {
+    const double rho = q0;
+    const double u = q1 / rho;
+    const double v = q2 / rho;
+    const double press = gamma1 * (q3 - 0.5 * rho * (u * u + v * v));
+    const double c = -dt * ndm1 / rad;
+    d[0] = c * q2;
+    d[1] = c * rho * u * v;
+    d[2] = c * rho * v * v;
+    d[3] = c * v * (q3 + press);
+}
+
 struct SweepArgs {
     const double *qin;
     double *qout;
@@ -84,7 +100,8 @@ struct SweepArgs {
     double dtd_t;     // dt/d of the transverse direction
     // (kept at the END of the block: the kernels' scalar loads of the fields above keep their offsets)
     // source term applied by the LAST pass of a dimension-split step while it stores its results (Godunov splitting,
-    // clawpack.py:156-159): 0 none, 1 euler_radial_source(gamma1, ndim-1), aux plane 0 = radial coordinate
+    // clawpack.py:156-159): 0 none, 1 euler_radial_source(gamma1, ndim-1), aux plane 0 = radial coordinate.  SharpClaw:
+    // 1 = euler_radial_dq added to deltaq by the last pass of a stage (sharpclaw.py:232-235, dq_src)
     int src_id;
     double src_p[2];
 };

@@ -37,6 +37,53 @@ def start_step(solver, solution):
     pass
 
 
+class DeviceDqSource(object):
+    """A SharpClaw source term (``solver.dq_src``) that libpyclaw_amd evaluates on the device.
+
+    It is also a plain ``dq_src(solver,state,dt)`` callable (numpy, same arithmetic), which is what runs -- through
+    the host, like any Python ``dq_src`` -- for a configuration the device kernel is not built for."""
+
+    src_id = 0
+
+    def fusable(self, solver, state):
+        return False
+
+    def __call__(self, solver, state, dt):
+        raise NotImplementedError
+
+
+class EulerRadialDqSource(DeviceDqSource):
+    """Geometric source of the 2-D Euler equations with radial symmetry in SharpClaw form -- the ``dq_Euler_radial``
+    callback of the shock-bubble app (apps/euler/2d/shockbubble/shockbubble.py:95-122).  aux[0] must hold the radial
+    coordinate.  With euler_5wave_2d, WENO5 and no capacity function the last pass of every stage adds it while
+    storing deltaq (``pcl_sharp_fuse_dq_src``): no extra pass over q."""
+
+    src_id = 1
+
+    def __init__(self, gamma1, ndim=2):
+        self.gamma1 = float(gamma1)
+        self.ndim = int(ndim)
+        self.params = np.array([self.gamma1, float(self.ndim)], dtype=np.float64)
+
+    def fusable(self, solver, state):
+        return (solver.ndim == 2 and riemann.get(solver.rp).name == 'euler_5wave_2d' and solver.lim_type == 2
+                and solver.weno_order == 5 and state.mcapa < 0 and state.maux >= 1)
+
+    def __call__(self, solver, state, dt):
+        q, rad = state.q, state.aux[0, :, :]
+        rho = q[0, :, :]
+        u = q[1, :, :] / rho
+        v = q[2, :, :] / rho
+        press = self.gamma1 * (q[3, :, :] - 0.5 * rho * (u ** 2 + v ** 2))
+        dq = np.empty(q.shape)
+        dq[0, :, :] = -dt * (self.ndim - 1) / rad * q[2, :, :]
+        dq[1, :, :] = -dt * (self.ndim - 1) / rad * rho * u * v
+        dq[2, :, :] = -dt * (self.ndim - 1) / rad * rho * v * v
+        dq[3, :, :] = -dt * (self.ndim - 1) / rad * v * (q[3, :, :] + press)
+        dq[4:, :, :] = 0
+        return dq
+
+
 class _StageState(object):
     """What a Python custom-BC callback sees of an RK stage: time, grid, aux (solver.py:283-291)."""
 
@@ -91,9 +138,9 @@ class SharpClawSolver(Solver):
             self.start_step(self, solution)
         t, dt = state.t, self.dt
         # st(reg, t, op, D, A, B, ...): deltaq = dq(reg, t) followed by the combination that consumes it.
-        # Without a Python dq_src both run as ONE fused device stage (pcl_sharp_stage); with one, deltaq
-        # has to visit the host and the combination is a separate register operation.
-        st = self._stage_fused if self.dq_src is None else self._stage_split
+        # Without a Python dq_src (or with a DeviceDqSource the last pass evaluates) both run as ONE fused device stage
+        # (pcl_sharp_stage); with one, deltaq has to visit the host and the combination is a separate register operation.
+        st = self._stage_fused if (self.dq_src is None or self._dq_src_fused) else self._stage_split
         try:
             if self.time_integrator == 'Euler':
                 st(Q, t, 1, Q, Q, Q, ca=1.0)                          # state.q += deltaq
@@ -163,7 +210,7 @@ class SharpClawSolver(Solver):
         self.dq_hyperbolic(reg, t)
         if self.cfl.get_cached_max() > self.cfl_max:
             raise CFLError('cfl_max exceeded')
-        if self.dq_src is not None:
+        if self.dq_src is not None and not self._dq_src_fused:
             # arbitrary Python: round trip of the stage through the host
             L = _lib.lib()
             st = self._stage
@@ -265,6 +312,11 @@ class SharpClawSolver(Solver):
         _lib.check(_lib.lib().pcl_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
         self._stage = _StageState(state)
+        self._dq_src_fused = False
+        if isinstance(self.dq_src, DeviceDqSource) and self.dq_src.fusable(self, state):
+            _lib.check(_lib.lib().pcl_sharp_fuse_dq_src(self._h, self.dq_src.src_id, _lib.d(self.dq_src.params),
+                                                        len(self.dq_src.params)))
+            self._dq_src_fused = True
         self.allocate_bc_arrays(state)
         self._setup_halo(state)
         self._upload_aux(state)

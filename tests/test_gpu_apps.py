@@ -319,3 +319,61 @@ def test_fused_source_when_cfl_equals_cfl_max(monkeypatch):
         claw.solver.teardown()
     assert out["1"][2] == out["0"][2] and out["1"][1] == out["0"][1]
     assert np.array_equal(out["1"][0], out["0"][0])
+
+
+@pytest.mark.parametrize("ti", ["SSP104", "SSP33", "Euler"])
+def test_sharpclaw_shockbubble_dq_src(coracle, ti):
+    """apps/euler/2d/shockbubble/shockbubble.py:173-176: SharpClawSolver2D (WENO5) with dq_src = dq_Euler_radial.  The
+    device twin evaluated inside the last pass of every stage (pcl_sharp_fuse_dq_src) == the numpy callback through
+    the host == the oracle driver's replay, bit for bit, for every RK combination the pass can end in."""
+    import pyclaw_amd as pyclaw
+    cfl = {} if ti == "SSP104" else dict(cfl_max=0.5, cfl_desired=0.45)    # the low-stage schemes need a smaller step
+    res = {}
+    for dev in (True, False):
+        claw = problems.shockbubble(pyclaw, mx=96, my=40, tfinal=0.1, device_callbacks=dev, solver_type='sharpclaw',
+                                    time_integrator=ti, dt_initial=0.002, run=False)
+        for k, v in cfl.items():
+            setattr(claw.solver, k, v)
+        claw.run()
+        assert claw.solver._dq_src_fused == dev
+        res[dev] = (claw.frames[claw.nout].state.q.copy(), dict(claw.solver.status))
+    assert res[True][1] == res[False][1]
+    assert np.array_equal(res[True][0], res[False][0])
+    p = D.shockbubble_problem(mx=96, my=40, solver_type='sharpclaw', time_integrator=ti, dt_initial=0.002, **cfl)
+    st = D.run(p, coracle, 0.1, 1)[-1]
+    assert res[True][1]["numsteps"] == st["numsteps"] and res[True][1]["numsteps"] > 3
+    assert np.array_equal(res[True][0], p.q)
+    # and the source is not a no-op
+    q_nosrc = problems.shockbubble(pyclaw, mx=96, my=40, tfinal=0.1, device_callbacks=True, solver_type='sharpclaw',
+                                   time_integrator=ti, dt_initial=0.002, with_src=False, run=False)
+    for k, v in cfl.items():
+        setattr(q_nosrc.solver, k, v)
+    q_nosrc.run()
+    assert np.abs(q_nosrc.frames[1].state.q - res[True][0]).max() > 1e-5
+
+
+def test_device_dq_source_falls_back_to_host_when_not_fusable():
+    """EulerRadialDqSource on a configuration the fused kernel is not built for (lim_type 1, the tvd2 reconstruction) runs as the numpy
+    callable it also is; pcl_sharp_fuse_dq_src itself refuses that configuration."""
+    import ctypes
+    import pyclaw_amd as pyclaw
+    from pyclaw_amd import _lib
+    claw = problems.shockbubble(pyclaw, mx=64, my=32, tfinal=0.01, device_callbacks=True, solver_type='sharpclaw',
+                                dt_initial=0.002, run=False)
+    claw.solver.lim_type = 1
+    ref = problems.shockbubble(pyclaw, mx=64, my=32, tfinal=0.01, device_callbacks=False, solver_type='sharpclaw',
+                               dt_initial=0.002, run=False)
+    ref.solver.lim_type = 1
+    claw.run()
+    ref.run()
+    assert not claw.solver._dq_src_fused
+    assert np.isfinite(ref.frames[1].state.q).all()
+    assert np.array_equal(claw.frames[1].state.q, ref.frames[1].state.q)
+    src = claw.solver.dq_src
+    claw2 = problems.shockbubble(pyclaw, mx=64, my=32, tfinal=0.01, device_callbacks=True, solver_type='sharpclaw',
+                                 run=False)
+    claw2.solver.lim_type = 1
+    claw2.solver.setup(claw2.solution)
+    rc = _lib.lib().pcl_sharp_fuse_dq_src(claw2.solver._h, 1, _lib.d(src.params), 2)
+    assert rc != 0
+    claw2.solver.teardown()
