@@ -106,9 +106,20 @@ __device__ __forceinline__ double dsqrt_pos(double x) { return dsqrt_pos_h(x).g;
 //    q0 = n*r, q = fma(fma(-d,q0,n), r, q0) is the same correctly rounded quotient
 //    (Markstein's theorem; r is 1/d to within an ulp after two Newton steps).
 // So: Recip(d) = v_rcp_f64 + 4 fma, each quotient = mul + 2 fma.  Outside the normal range
-// the result differs from IEEE (e.g. n/0 gives NaN instead of inf): only reached by states
-// that are already unphysical.  The limiter ratio (philim), whose operands are sums of
+// the result differs from IEEE: a zero / inf / NaN denominator (n/0 gives NaN instead of inf) is only
+// reached by states that are already unphysical; a NUMERATOR in the underflow range (a momentum of 1e-310
+// ahead of a front) is physical, and there the quotient can be one step of the denormal grid off -- see
+// PCL_DENORM_GUARD below for the measured size of that and the build that removes it.  The limiter ratio (philim), whose operands are sums of
 // squares that can legitimately underflow, keeps the full IEEE division in exact mode.
+// PCL_DENORM_GUARD=1 (make GUARD=1): quotients whose numerator lies in the underflow range take the IEEE division too.
+// Off by default: measured on MI355X it costs the VALU-bound kernels 3-5 % (dense state x +3.1 % / y +5.0 %, unsplit
+// x phase +6.7 %; the memory-bound shock-bubble headline nothing), and what it buys is at most one step of the denormal
+// grid per quotient: without it 952 of 5.1e6 values of tools/probe_denormal.py differ from the oracle, all below 1e-290
+// in magnitude, by at most 3.2e-322; with it none do (profiles/r02_denorm_guard_ab.txt).  tests/test_gpu_fuzz.py pins
+// that bound.
+#ifndef PCL_DENORM_GUARD
+#define PCL_DENORM_GUARD 0
+#endif
 struct Recip {
     double d, r;
     // From a seed y0 that is already 1/den to a few 2^-48 (a by-product of a square root of the same quantity, or
@@ -137,6 +148,16 @@ struct Recip {
 #if PCL_FAST
         return n * r;  // within ~1 ulp, not correctly rounded
 #else
+#if PCL_DENORM_GUARD
+        // a numerator deep in the underflow range (|n| < 2^-960, not zero: the tail of a momentum or tracer field
+        // ahead of a front): the residual below would itself underflow and the quotient could be off by one step of
+        // the denormal grid -- take the IEEE division.  frexp_exp is 0 for n == 0, so quiescent regions stay on the
+        // fast path; the empty asm keeps this a (practically never taken) branch instead of a select.
+        if (__builtin_expect(__builtin_amdgcn_frexp_exp(n) < -960, 0)) {
+            asm volatile("");
+            return n / d;
+        }
+#endif
         const double q = n * r;
         return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 #endif

@@ -223,3 +223,47 @@ def test_fuzz_step3_unsplit(coracle, seed):
     assert np.array_equal(out[inner], ref[inner]), "seed %d n %s trans %d: max diff %g" % (
         seed, n, trans, np.abs(out[inner] - ref[inner]).max())
     assert cfl.value == cfl_ref
+
+
+def test_underflow_range_operands_stay_within_one_denormal_step(coracle):
+    """Momenta and tracer in the underflow range (1e-295 .. 5e-324: the leading tail of a front).  The exact build's
+    shared-reciprocal quotients (rp.hpp Recip) are correctly rounded for normal-range numerators; below that a
+    quotient may land one step of the denormal grid away from the IEEE result.  Pinned here: whatever differs from
+    the oracle is itself of underflow magnitude and differs by < 1e-320 (measured: 952 of 5.1e6 values, <= 3.2e-322);
+    the Courant number is identical.  A GUARD=1 build (csrc/Makefile) has no differences at all."""
+    L = _lib()
+    ndiff = 0
+    for seed in range(12):
+        rng = np.random.default_rng(seed)
+        mx, my = int(rng.integers(30, 200)), int(rng.integers(30, 200))
+        mbc = 2
+        shape = (mx + 4, my + 4)
+        rho = 0.5 + rng.random(shape)
+        p = 0.3 + rng.random(shape)
+        mode = seed % 3
+        u = (rng.random(shape) - 0.5) * (10.0 ** rng.uniform(-323, -295, shape) if mode != 1 else 1.0)
+        v = (rng.random(shape) - 0.5) * (10.0 ** rng.uniform(-323, -295, shape) if mode != 2 else 1.0)
+        q0 = np.empty((5,) + shape, order="F")
+        q0[0] = rho
+        q0[1] = rho * u
+        q0[2] = rho * v
+        q0[3] = p / 0.4 + 0.5 * rho * (u * u + v * v)
+        q0[4] = rng.random(shape) * 10.0 ** rng.uniform(-323, -300, shape)
+        par = np.array([1.4, 0.4])
+        mth = np.array([4, 4, 4, 4, 2], dtype=np.int32)
+        method = np.array([1, 2, -1, 0, 0, 0, 0], dtype=np.int32)
+        dx, dy, dt = 1.0 / mx, 0.7 / my, 0.04 / max(mx, my)
+        for ids in (1, 2):
+            ref = q0.copy("F")
+            _, cfl_ref = coracle.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), ref, None, dx, dy,
+                                         dt, method, mth, ids)
+            out = q0.copy("F")
+            cfl = C.c_double()
+            L.check(L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(par), 0, 5, 5, 0, mbc, mx, my, L.d(q0), L.d(out), None, dx, dy,
+                                        dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp), ids))
+            assert cfl.value == cfl_ref
+            bad = out != ref
+            ndiff += int(bad.sum())
+            if bad.any():
+                assert np.abs(ref[bad]).max() < 1e-290 and np.abs(out[bad] - ref[bad]).max() < 1e-320
+    assert ndiff < 2000
