@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--state", choices=["bubble", "dense", "developed"], default="bubble",
                     help="state the main timed run starts from (profile runs of the dense / developed state: "
                          "tools/profile_round.sh); anything but bubble implies --no-states")
-    ap.add_argument("--math", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--math", choices=["exact", "fast", "strict"], default="exact")
     ap.add_argument("--unsplit", action="store_true", help="unsplit algorithm with order_trans=2 (not the headline)")
     ap.add_argument("--extras", action="store_true",
                     help="also time the fast arithmetic mode (fast_math object)")
@@ -460,6 +460,7 @@ def main():
                                    "mthlim=[4,4,4,4,2], order 2, source off"
                                    % (grid_note, "UNSPLIT order_trans=2" if args.unsplit else "dim-split"),
                        "global_grid": [nxg, nyg] + ([args.nx * dims[2]] if args.ndim == 3 else []), "proc_grid": dims, "math": ("exact (no FMA, IEEE div/sqrt; bit-identical to the reference)" if args.math == "exact"
+                                else "strict (exact + IEEE quotients for underflow-range numerators)" if args.math == "strict"
                                 else "fast (FMA contraction, reciprocal-multiply division; rtol 1e-12 vs reference)"),
                        "halo_transport": getattr(claw.solver, "halo_transport", "none (one block)"),
                        "launches_timed": {names[0]: int(nl[0]), names[1]: int(nl[1])},

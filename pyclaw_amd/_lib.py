@@ -49,6 +49,7 @@ PROTOTYPES = {
     "pcl_version": (C.c_int, []),
     "pcl_device_count": (C.c_int, []),
     "pcl_layer1_release": (None, []),
+    "pcl_layer1_math": (C.c_int, [C.c_int]),
     "pcl_step1": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp,
                             C.c_double, C.c_double, ip, ip, dp]),
     "pcl_step1fw": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp,

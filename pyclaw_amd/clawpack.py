@@ -225,9 +225,9 @@ class ClawSolver(Solver):
             cfg.rp_params[k] = v
         from . import parallel
         cfg.device = parallel.device_ordinal() if state.decomp is not None else int(getattr(self, 'device', 0))
-        if self.math not in ('exact', 'fast'):
-            raise Exception("solver.math must be 'exact' or 'fast'")
-        cfg.math = 1 if self.math == 'fast' else 0
+        if self.math not in ('exact', 'fast', 'strict'):
+            raise Exception("solver.math must be 'exact', 'fast' or 'strict'")
+        cfg.math = {'exact': 0, 'fast': 1, 'strict': 2}[self.math]
         import ctypes
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().pcl_create(ctypes.byref(cfg), ctypes.byref(h)))

@@ -78,6 +78,9 @@ static inline double *&cur(pcl_solver *s) { return s->sel == 0 ? s->q : s->sreg[
 static inline bool timing_on(const pcl_solver *s) { return s->timing > 0 && s->step_no % s->timing == 0; }
 
 namespace pcl { namespace exact { void launch_shift_test(const double *in, double *l, double *r); } }
+// one launcher per arithmetic mode (kernels.hip is compiled once per mode)
+#define PCL_BY_MATH(math, call) \
+    ((math) == PCL_MATH_FAST ? pcl::fast::call : (math) == PCL_MATH_STRICT ? pcl::strict::call : pcl::exact::call)
 
 namespace {
 
@@ -394,7 +397,7 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
     l.fwave = s->cfg.fwave;
     l.stream = stream;
     std::string err;
-    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sweep(l, err) : pcl::exact::launch_sweep(l, err);
+    int rc = PCL_BY_MATH(s->cfg.math, launch_sweep(l, err));
     if (rc) fail(rc, err);
     if (timed) {
         hipEventRecord(t.b, stream);
@@ -436,7 +439,7 @@ int do_sweep3(pcl_solver *s, const double *qin, double *qout, int dir, double dt
     l.fwave = s->cfg.fwave;
     l.stream = s->stream;
     std::string err;
-    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sweep3(l, err) : pcl::exact::launch_sweep3(l, err);
+    int rc = PCL_BY_MATH(s->cfg.math, launch_sweep3(l, err));
     if (rc) fail(rc, err);
     if (timing_on(s)) {
         hipEventRecord(t.b, s->stream);
@@ -481,7 +484,7 @@ int do_unsplit3(pcl_solver *s, double dt) {
         (void)mbc;
         pcl_solver::Timed t{};
         if (timing_on(s)) { t.a = get_event(s); t.b = get_event(s); t.which = dir == 1 ? 0 : 1; t.count = true; hipEventRecord(t.a, s->stream); }
-        int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit3(l, err) : pcl::exact::launch_unsplit3(l, err);
+        int rc = PCL_BY_MATH(s->cfg.math, launch_unsplit3(l, err));
         if (timing_on(s)) { hipEventRecord(t.b, s->stream); s->timed.push_back(t); }
         if (rc) return fail(rc, err);
     }
@@ -511,8 +514,7 @@ static int unsplit_phase(pcl_solver *s, int ids, double dt, int sub, hipStream_t
     l.ndim = 2; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave; l.stream = stream;
     pcl_solver::Timed t{};
     if (timing_on(s)) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
-    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_unsplit(l, s->t1, err)
-                                          : pcl::exact::launch_unsplit(l, s->t1, err);
+    int rc = PCL_BY_MATH(s->cfg.math, launch_unsplit(l, s->t1, err));
     if (timing_on(s)) { hipEventRecord(t.b, stream); s->timed.push_back(t); }
     if (rc) return fail(rc, err);
     return PCL_OK;
@@ -630,7 +632,8 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->lim_type == 1 && cfg->meqn > PCL_MAX_WAVES)
         return fail(PCL_EINVAL, "SharpClaw tvd2: mthlim is indexed by component, meqn <= PCL_MAX_WAVES");
     if (cfg->mwaves < 1 || cfg->mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
-    if (cfg->math != PCL_MATH_EXACT && cfg->math != PCL_MATH_FAST) return fail(PCL_EINVAL, "unknown math mode");
+    if (cfg->math != PCL_MATH_EXACT && cfg->math != PCL_MATH_FAST && cfg->math != PCL_MATH_STRICT)
+        return fail(PCL_EINVAL, "unknown math mode");
     int want_meqn = 0, want_mwaves = 0, want_ndim = 0;
     switch (cfg->rp) {
     case PCL_RP_ADVECTION_1D: want_meqn = 1; want_mwaves = 1; want_ndim = 1; break;
@@ -1255,7 +1258,7 @@ static int sharp_pass(pcl_solver *s, int ids, double dt, int rk_op, const double
     l.lim_type = s->cfg.lim_type; l.stream = stream;
     pcl_solver::Timed t{};
     if (timing_on(s)) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
-    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_sharp(l, err) : pcl::exact::launch_sharp(l, err);
+    int rc = PCL_BY_MATH(s->cfg.math, launch_sharp(l, err));
     if (timing_on(s)) { hipEventRecord(t.b, stream); s->timed.push_back(t); if (s->timed.size() >= 2048) drain_timing(s); }
     if (rc) return fail(rc, err);
     return PCL_OK;
@@ -1416,7 +1419,7 @@ int pcl_rk_op(pcl_solver *s, int op, int D, int A, int B, int Cc, double ca, dou
     r.n = s->total;
     HIP_TRY(hipSetDevice(s->cfg.device));
     std::string err;
-    int rc = s->cfg.math == PCL_MATH_FAST ? pcl::fast::launch_rk(r, s->stream, err) : pcl::exact::launch_rk(r, s->stream, err);
+    int rc = PCL_BY_MATH(s->cfg.math, launch_rk(r, s->stream, err));
     if (rc) return fail(rc, err);
     return PCL_OK;
 }
@@ -1493,6 +1496,7 @@ bool same_shape(const pcl_config &a, const pcl_config &b) {
            a.method[5] == b.method[5] && (a.method[2] < 0) == (b.method[2] < 0);
 }
 // a handle for this configuration: the cached one (its scalars refreshed) or a new one that replaces it
+int g_l1_math = PCL_MATH_EXACT;     // arithmetic mode of the f2py-shaped calls (pcl_layer1_math)
 int layer1_handle(const pcl_config &c, pcl_solver **out) {
     if (g_l1.s && same_shape(g_l1.s->cfg, c)) {
         g_l1.s->cfg = c;      // method, mthlim, rp_params, d: read at launch time only
@@ -1507,6 +1511,12 @@ int layer1_handle(const pcl_config &c, pcl_solver **out) {
     return PCL_OK;
 }
 }  // namespace
+
+int pcl_layer1_math(int math) {
+    if (math != PCL_MATH_EXACT && math != PCL_MATH_FAST && math != PCL_MATH_STRICT) return fail(PCL_EINVAL, "unknown math mode");
+    g_l1_math = math;
+    return PCL_OK;
+}
 
 void pcl_layer1_release(void) {
     if (g_l1.s) { pcl_destroy(g_l1.s); g_l1.s = nullptr; }
@@ -1527,7 +1537,7 @@ static int host_sweep(int ndim, int rp, const double *rp_params, int fwave, int 
     for (int k = 0; k < mwaves; k++) c.mthlim[k] = mthlim[k];
     c.fwave = fwave; c.rp = rp;
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
-    c.d[0] = dx; c.d[1] = dy; c.device = 0; c.math = PCL_MATH_EXACT;
+    c.d[0] = dx; c.d[1] = dy; c.device = 0; c.math = g_l1_math;
     // The Fortran updates qnew IN PLACE (qnew = qnew + increments computed from qold).  Both callers of the reference
     // pass qnew == qold on entry -- a copy (clawpack.py:529-530,538-541) or the same array (:542-543); the device path
     // starts from qold, so anything else is refused instead of silently ignored.
@@ -1590,7 +1600,7 @@ int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux,
     for (int k = 0; k < mwaves; k++) c.mthlim[k] = mthlim[k];
     c.rp = rp;
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
-    c.d[0] = dx; c.d[1] = dy; c.d[2] = dz; c.math = PCL_MATH_EXACT;
+    c.d[0] = dx; c.d[1] = dy; c.d[2] = dz; c.math = g_l1_math;
     pcl_solver *s = nullptr;
     if (int rc = layer1_handle(c, &s)) return rc;
     int rc = pcl_put_q(s, qold, 1);
@@ -1624,7 +1634,7 @@ int pcl_step3(int rp, const double *rp_params, int meqn, int mwaves, int maux, i
     for (int k = 0; k < mwaves; k++) c.mthlim[k] = mthlim[k];
     c.rp = rp;
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
-    c.d[0] = dx; c.d[1] = dy; c.d[2] = dz; c.math = PCL_MATH_EXACT;
+    c.d[0] = dx; c.d[1] = dy; c.d[2] = dz; c.math = g_l1_math;
     pcl_solver *s = nullptr;
     if (int rc = layer1_handle(c, &s)) return rc;
     int rc = pcl_put_q(s, qold, 1);
@@ -1646,7 +1656,7 @@ static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, i
     for (int k = 0; k < PCL_MAX_WAVES; k++) c.mthlim[k] = g_sharp_mthlim[k];
     c.rp = rp;
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];
-    c.d[0] = dx; c.d[1] = dy; c.kind = PCL_KIND_SHARPCLAW; c.lim_type = lim_type; c.math = PCL_MATH_EXACT;
+    c.d[0] = dx; c.d[1] = dy; c.kind = PCL_KIND_SHARPCLAW; c.lim_type = lim_type; c.math = g_l1_math;
     pcl_solver *s = nullptr;
     if (int rc = layer1_handle(c, &s)) return rc;
     int rc = pcl_put_q(s, q, 1);

@@ -111,8 +111,8 @@ __device__ __forceinline__ double dsqrt_pos(double x) { return dsqrt_pos_h(x).g;
 // ahead of a front) is physical, and there the quotient can be one step of the denormal grid off -- see
 // PCL_DENORM_GUARD below for the measured size of that and the build that removes it.  The limiter ratio (philim), whose operands are sums of
 // squares that can legitimately underflow, keeps the full IEEE division in exact mode.
-// PCL_DENORM_GUARD=1 (make GUARD=1): quotients whose numerator lies in the underflow range take the IEEE division too.
-// Off by default: measured on MI355X it costs the VALU-bound kernels 3-5 % (dense state x +3.1 % / y +5.0 %, unsplit
+// PCL_DENORM_GUARD=1 (the `strict` build of the kernels, PCL_MATH_STRICT): quotients whose numerator lies in the underflow range take the IEEE division too.
+// Not in the `exact` build: measured on MI355X it costs the VALU-bound kernels 3-5 % (dense state x +3.1 % / y +5.0 %, unsplit
 // x phase +6.7 %; the memory-bound shock-bubble headline nothing), and what it buys is at most one step of the denormal
 // grid per quotient: without it 952 of 5.1e6 values of tools/probe_denormal.py differ from the oracle, all below 1e-290
 // in magnitude, by at most 3.2e-322; with it none do (profiles/r02_denorm_guard_ab.txt).  tests/test_gpu_fuzz.py pins

@@ -158,5 +158,14 @@ int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  /
 int launch_sharp(const SweepLaunch &l, std::string &err);
 int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 }
+// exact + IEEE quotients for underflow-range numerators as well (rp.hpp PCL_DENORM_GUARD), PCL_MATH_STRICT
+namespace strict {
+int launch_sweep(const SweepLaunch &l, std::string &err);
+int launch_sweep3(const SweepLaunch &l, std::string &err);
+int launch_unsplit3(const Unsplit3Launch &l, std::string &err);
+int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);
+int launch_sharp(const SweepLaunch &l, std::string &err);
+int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
+}
 
 }  // namespace pcl

@@ -377,3 +377,18 @@ def test_device_dq_source_falls_back_to_host_when_not_fusable():
     rc = _lib.lib().pcl_sharp_fuse_dq_src(claw2.solver._h, 1, _lib.d(src.params), 2)
     assert rc != 0
     claw2.solver.teardown()
+
+
+def test_shockbubble_golden_strict_math(golden_dir):
+    """math='strict' (PCL_MATH_STRICT, the third build of the kernels: exact + IEEE quotients for underflow-range
+    numerators) gives the golden density bit for bit as well, classic and SharpClaw stage kernels both load."""
+    import pyclaw_amd as pyclaw
+    claw = problems.shockbubble(pyclaw, math='strict')
+    gold = np.loadtxt(os.path.join(golden_dir, "sb_density"))
+    assert np.array_equal(claw.frames[claw.nout].state.q[0, :, :], gold)
+    a = problems.acoustics2D(pyclaw, mx=40, my=40, solver_type='sharpclaw', tfinal=0.05, nout=1, run=False)
+    b = problems.acoustics2D(pyclaw, mx=40, my=40, solver_type='sharpclaw', tfinal=0.05, nout=1, run=False)
+    b.solver.math = 'strict'
+    a.run()
+    b.run()
+    assert np.array_equal(a.frames[1].state.q, b.frames[1].state.q)

@@ -225,13 +225,24 @@ def test_fuzz_step3_unsplit(coracle, seed):
     assert cfl.value == cfl_ref
 
 
-def test_underflow_range_operands_stay_within_one_denormal_step(coracle):
+@pytest.mark.parametrize("math", ["exact", "strict"])
+def test_underflow_range_operands_stay_within_one_denormal_step(coracle, math):
     """Momenta and tracer in the underflow range (1e-295 .. 5e-324: the leading tail of a front).  The exact build's
     shared-reciprocal quotients (rp.hpp Recip) are correctly rounded for normal-range numerators; below that a
     quotient may land one step of the denormal grid away from the IEEE result.  Pinned here: whatever differs from
     the oracle is itself of underflow magnitude and differs by < 1e-320 (measured: 952 of 5.1e6 values, <= 3.2e-322);
-    the Courant number is identical.  A GUARD=1 build (csrc/Makefile) has no differences at all."""
+    the Courant number is identical.  math = 'strict' (PCL_MATH_STRICT: the same kernels with an IEEE branch for such
+    numerators) has no differences at all."""
     L = _lib()
+    L.check(L.lib().pcl_layer1_math(2 if math == "strict" else 0))
+    try:
+        ndiff = _underflow_sweeps(L, coracle)
+    finally:
+        L.check(L.lib().pcl_layer1_math(0))
+    assert ndiff < 2000 if math == "exact" else ndiff == 0
+
+
+def _underflow_sweeps(L, coracle):
     ndiff = 0
     for seed in range(12):
         rng = np.random.default_rng(seed)
@@ -266,4 +277,4 @@ def test_underflow_range_operands_stay_within_one_denormal_step(coracle):
             ndiff += int(bad.sum())
             if bad.any():
                 assert np.abs(ref[bad]).max() < 1e-290 and np.abs(out[bad] - ref[bad]).max() < 1e-320
-    assert ndiff < 2000
+    return ndiff
