@@ -181,6 +181,21 @@ def pmc_traffic(math, which, nx, ny, state="bubble"):
     return None, None
 
 
+def copy_ceiling():
+    """What a pure 5-planes-in / 5-planes-out copy of the sweep's tile shape reaches on an MI355X (nontemporal accesses),
+    from the committed run of tools/ubench/copy_rates.hip: the practical ceiling next to the 8 TB/s data-sheet peak.
+    Returns (GB/s or None, source)."""
+    try:
+        best = 0.0
+        with open(os.path.join(ROOT, "profiles", "r02_copy_rates.txt")) as f:
+            for line in f:
+                if line.startswith("tile") and "GB/s" in line:
+                    best = max(best, float(line.split()[-2]))
+        return (best or None), "profiles/r02_copy_rates.txt (tools/ubench/copy_rates.hip, best tile-shaped copy)"
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(nx, ny, max_seconds=30.0):
     """Time the reference's CPU path on ONE core on a bounded sample of the same workload:
     whole dim-split steps (x then y sweep) of the same Euler state on an nx x (rows) slab.
@@ -471,6 +486,9 @@ def main():
                          "avg_ms": {names[0]: avg[0], names[1]: avg[1]},
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
+        ceil, ceil_src = copy_ceiling()
+        if ceil:        # documentary: the fraction of what a plain copy reaches; `frac` stays against the 8 TB/s peak
+            out["roofline"]["copy_ceiling"] = {"GB/s": ceil, "frac_of_ceiling": achieved / ceil, "source": ceil_src}
         if args.solver == "sharpclaw":
             out["metric"] = "Mcell*steps/s, 2-D Euler SharpClaw WENO5 + SSP104 step (10 right-hand sides per step)"
             out["config"]["workload"] = ("apps/euler 2D shock-bubble, %dx%d cells, SharpClaw lim_type=2 (WENO5), "
