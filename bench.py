@@ -553,7 +553,10 @@ def main():
                            "avg_ms": {"x pass": avg2[0], "y pass": avg2[1]}, "result_finite": fin2}
             out["fast_math"] = fm
         if args.ndim == 3:
-            out["metric"] = "Mcell*steps/s, 3-D acoustics classic dim-split step (+ achieved HBM GB/s in roofline)"
+            out["metric"] = ("Mcell*steps/s, 3-D acoustics classic %s step (+ achieved HBM GB/s in roofline)"
+                             % ("UNSPLIT (step3, order_trans 22)" if args.unsplit else "dim-split (step3ds)"))
+        elif args.unsplit and args.solver == "classic" and args.app == "bubble":
+            out["metric"] = "Mcell*steps/s, 2-D Euler classic UNSPLIT step (step2, order_trans 2) (+ achieved HBM GB/s in roofline)"
         if size == 1 and not args.no_cpu_baseline and args.ndim == 2 and args.solver == "classic" and args.app == "bubble":
             try:
                 out["cpu_baseline"] = cpu_baseline(args.nx, args.ny)

@@ -521,12 +521,12 @@ def acoustics3d_problem(test='hom', mx=None, my=None, mz=None, **kw):
                    order_trans=22, **kw)
 
 
-def shallow_sphere_problem(setup_backend, mx=40, my=20, Rsphere=1.0):
+def shallow_sphere_problem(setup_backend, mx=40, my=20, Rsphere=1.0, solver_type='classic'):
     """test/shallow_sphere/shallow_4_Rossby_Haurwitz_wave.py:343-484: 4-Rossby-Haurwitz wave on the sphere, classic
     unsplit (step2qcor) with order_trans=2, MC limiter, capa = aux[0], Strang splitting of the Coriolis source.
     `setup_backend` supplies setaux / qinit / src2 (the C restatement, or the reference's own problem.so)."""
     from oracle.oracle import RP_SHALLOW_SPHERE_2D
-    mbc = 2
+    mbc = 2 if solver_type == 'classic' else 3
     xlower, xupper, ylower, yupper = -3.0, 1.0, -1.0, 1.0
     dx, dy = (xupper - xlower) / float(mx), (yupper - ylower) / float(my)
     auxtmp = setup_backend.sphere_setaux(mbc, mx, my, xlower, ylower, dx, dy, Rsphere)     # with ghost cells
@@ -555,6 +555,16 @@ def shallow_sphere_problem(setup_backend, mx=40, my=20, Rsphere=1.0):
         setup_backend.sphere_src2(qf, np.asfortranarray(auxv), xlower, ylower, dx, dy, dt, Rsphere)
         qv[...] = qf
 
+    if solver_type == 'sharpclaw':
+        # BASELINE configs[4]'s synthetic variant (apps/shallow_sphere.py): WENO5 + SSP104 on the same data, SharpClaw
+        # defaults (sharpclaw.py:127-146), no source term
+        return Problem(
+            q=q, aux=aux, d=(dx, dy), rp=RP_SHALLOW_SPHERE_2D, rp_params=[11489.57219, dx, dy], mwaves=3, limiters=[1],
+            solver_type='sharpclaw', lim_type=2, mcapa=0, cfl_max=2.5, cfl_desired=2.45,
+            bc_lower=[PERIODIC, CUSTOM], bc_upper=[PERIODIC, CUSTOM],
+            user_bc_lower=qbc_lower_y, user_bc_upper=qbc_upper_y,
+            aux_bc_lower=[PERIODIC, CUSTOM], aux_bc_upper=[PERIODIC, CUSTOM],
+            user_aux_bc_lower=auxbc_lower_y, user_aux_bc_upper=auxbc_upper_y)
     return Problem(
         q=q, aux=aux, d=(dx, dy), rp=RP_SHALLOW_SPHERE_2D, rp_params=[11489.57219, dx, dy], mwaves=3, limiters=4,
         dim_split=False, order_trans=2, src_split=2, step_src=src, mcapa=0, qcor=True,

@@ -325,16 +325,18 @@ class RefEuler2D:
     class _CParam(C.Structure):
         _fields_ = [("gamma", C.c_double), ("gamma1", C.c_double)]
 
-    def __init__(self, path=None):
-        path = path or os.path.join(_HERE, "_ref", "libref_euler2d.so")
+    def __init__(self, path=None, fwave=False):
+        """fwave=True: the classic2fw link (flux2fw.f in place of flux2.f, oracle/Makefile: libref_euler2d_fw.so)"""
+        path = path or os.path.join(_HERE, "_ref", "libref_euler2d_fw.so" if fwave else "libref_euler2d.so")
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.lib = C.CDLL(path)
+        self.fwave = bool(fwave)
         self.cparam = self._CParam.in_dll(self.lib, "cparam_")
 
     @staticmethod
-    def available():
-        return os.path.exists(os.path.join(_HERE, "_ref", "libref_euler2d.so"))
+    def available(fwave=False):
+        return os.path.exists(os.path.join(_HERE, "_ref", "libref_euler2d_fw.so" if fwave else "libref_euler2d.so"))
 
     def _call(self, name, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim, ids):
         self.cparam.gamma, self.cparam.gamma1 = float(par[0]), float(par[1])
@@ -371,13 +373,13 @@ class RefEuler2D:
 
     def step2ds(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim, ids,
                 fwave=False):
-        assert rp == RP_EULER5_2D and not fwave
+        assert rp == RP_EULER5_2D and bool(fwave) == self.fwave
         return self._call("step2ds_", par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method,
                           mthlim, ids)
 
     def step2(self, rp, par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method, mthlim,
               fwave=False):
-        assert rp == RP_EULER5_2D and not fwave
+        assert rp == RP_EULER5_2D and bool(fwave) == self.fwave
         return self._call("step2_", par, maxm, mbc, mx, my, qold, qnew, aux, dx, dy, dt, method,
                           mthlim, None)
 

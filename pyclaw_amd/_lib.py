@@ -141,6 +141,10 @@ def lib():
             f.restype = res
             f.argtypes = args
         _lib = L
+        # the cached device handle of the f2py-shaped calls is freed while the HIP runtime is still alive (the
+        # library itself makes no HIP call from a static destructor)
+        import atexit
+        atexit.register(L.pcl_layer1_release)
     return _lib
 
 

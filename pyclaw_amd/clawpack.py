@@ -69,6 +69,8 @@ class ClawSolver(Solver):
         self._default_attr_values['math'] = 'exact'
         self.rp = None
         self._src_fused = False
+        self._fuse_key = None
+        self._rp_id = None
         self._cfl_out = None
         self._cfl_ptr = None
         super(ClawSolver, self).__init__(data)
@@ -77,6 +79,8 @@ class ClawSolver(Solver):
     def step(self, solution):
         r"""clawpack.py:114-165"""
         state = solution.states[0]
+        if self._fuse_key != (id(self.step_src), self.src_split):      # changed after setup(): decide again
+            self._decide_src_fusion(state)
         if self.start_step is not None:
             self._pull(state)
             self.start_step(self, solution)
@@ -236,14 +240,23 @@ class ClawSolver(Solver):
         self.allocate_bc_arrays(state)
         self._setup_halo(state)
         self._upload_aux(state)
-        # Godunov-split device source of the 2-D Euler step: applied by the y pass / y phase while it stores its
-        # results (one read + write of q less per step; PCL_FUSE_SRC=0 keeps the separate source kernel)
+        self._rp_id = rp.id
+        self._src_fused = False          # a fresh device handle
+        self._decide_src_fusion(state)
+
+    def _decide_src_fusion(self, state):
+        """Godunov-split device source of the 2-D Euler step: applied by the y pass / y phase while it stores its
+        results (one read + write of q less per step; PCL_FUSE_SRC=0 keeps the separate source kernel).  Decided at
+        setup and again by step() whenever step_src / src_split were changed afterwards."""
         import os
-        self._src_fused = False
-        if (isinstance(self.step_src, EulerRadialSource) and self.src_split == 1 and self.ndim == 2
-                and rp.id == 11 and state.mcapa < 0 and os.environ.get("PCL_FUSE_SRC", "1") != "0"):
+        fuse = (isinstance(self.step_src, EulerRadialSource) and self.src_split == 1 and self.ndim == 2
+                and self._rp_id == 11 and state.mcapa < 0 and os.environ.get("PCL_FUSE_SRC", "1") != "0")
+        if fuse:
             _lib.check(_lib.lib().pcl_fuse_source(self._h, 1, _lib.d(self.step_src.params), 2))
-            self._src_fused = True
+        elif self._src_fused:
+            _lib.check(_lib.lib().pcl_fuse_source(self._h, 0, None, 0))
+        self._src_fused = bool(fuse)
+        self._fuse_key = (id(self.step_src), self.src_split)
 
     def teardown(self):
         super(ClawSolver, self).teardown()

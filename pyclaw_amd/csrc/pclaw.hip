@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -371,9 +372,11 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
     SweepArgs a = make_args(s, qin, qout, ids, dt);
     a.sub = sub;
     if (sub) for (int k = 0; k < 4; k++) a.box[k] = box[k];
-    if (s->cfg.mbc > 2 && s->cfg.ndim <= 2 && sub != 2) {
+    if (s->cfg.mbc > 2 && s->cfg.ndim <= 2 && sub != 1) {
         // more than two ghost layers: the sweep kernels copy through the two layers their strips hold; the outer
-        // layers of qnew are copies of qold as well (step2ds.f / step1.f update interior cells of a copy)
+        // layers of qnew are copies of qold as well (step2ds.f / step1.f update interior cells of a copy).
+        // In an overlapped decomposed step the copy goes with the RIM launch (sub == 2), i.e. behind the halo exchange
+        // on its stream: the interior launch (sub == 1) runs while the unpack writes those very ghost cells of qin.
         FrameBc f;
         for (int k = 0; k < 4; k++) { f.t[k] = -1; for (int m = 0; m < 8; m++) f.c[k][m] = 0.0; }
         hipLaunchKernelGGL(frame_kernel, dim3(frame_blocks(s)), dim3(256), 0, stream, const_cast<double *>(qin), qout,
@@ -1067,8 +1070,9 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
         int rc = PCL_OK;
         if (ov && seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);
         else if (ov) {
-            HIP_TRY(hipEventRecord(s->ev_h0, s->stream));            // q of the previous step is complete
-            HIP_TRY(hipStreamWaitEvent(hs, s->ev_h0, 0));
+            hipError_t he = hipEventRecord(s->ev_h0, s->stream);      // q of the previous step is complete
+            if (he == hipSuccess) he = hipStreamWaitEvent(hs, s->ev_h0, 0);
+            if (he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream fork: ") + hipGetErrorString(he));
         }
         if (!rc && s->halo.active && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, hs))
             rc = fail(PCL_ECOMM, err);
@@ -1088,7 +1092,7 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     }
     if (s->halo.active && !overlapped) {
         std::string err;
-        if (s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err)) return fail(PCL_ECOMM, err);
+        if (s->halo.exchange(cur(s), s->cfg.meqn, s->pitch, s->plane, err)) return bail(s, fail(PCL_ECOMM, err));
     }
     if (overlapped) {
         for (int k = 0; k < 4; k++) {
@@ -1105,11 +1109,15 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             rc = do_sweep(s, s->q, s->t1, 1, dt, 1, box);
             if (!rc && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err)) rc = fail(PCL_ECOMM, err);
         } else {
-            HIP_TRY(hipEventRecord(s->ev_h0, s->stream));          // q of the previous step is complete
-            HIP_TRY(hipStreamWaitEvent(s->hstream, s->ev_h0, 0));
+            hipError_t hf = hipEventRecord(s->ev_h0, s->stream);     // q of the previous step is complete
+            if (hf == hipSuccess) hf = hipStreamWaitEvent(s->hstream, s->ev_h0, 0);
+            if (hf != hipSuccess) {
+                s->vbc_on = 0;
+                return bail(s, fail(PCL_EHIP, std::string("halo stream fork: ") + hipGetErrorString(hf)));
+            }
             if (s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, s->hstream)) {
                 s->vbc_on = 0;
-                return fail(PCL_ECOMM, err);
+                return bail(s, fail(PCL_ECOMM, err));
             }
             rc = do_sweep(s, s->q, s->t1, 1, dt, 1, box);      // interior tiles, concurrent with the exchange
             // rim tiles (ghost frame + physical BCs) behind the exchange on ITS stream: they start as soon as
@@ -1317,8 +1325,9 @@ static int sharp_passes(pcl_solver *s, double dt, int rk_op, const double *ra, c
         const hipStream_t hs = seq ? s->stream : s->hstream;
         if (seq) rc = sharp_pass(s, 1, dt, rk_op, ra, rb, rd, ca, cb, cc, 1, s->stream);
         else {
-            HIP_TRY(hipEventRecord(s->ev_h0, s->stream));            // the stage register is complete
-            HIP_TRY(hipStreamWaitEvent(hs, s->ev_h0, 0));
+            hipError_t he = hipEventRecord(s->ev_h0, s->stream);      // the stage register is complete
+            if (he == hipSuccess) he = hipStreamWaitEvent(hs, s->ev_h0, 0);
+            if (he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream fork: ") + hipGetErrorString(he));
         }
         if (!rc) rc = sharp_frame(s, bc, cstate, hs);
         if (!rc && !seq) rc = sharp_pass(s, 1, dt, rk_op, ra, rb, rd, ca, cb, cc, 1, s->stream);
@@ -1481,13 +1490,18 @@ int pcl_debug_wave_shift(const double *in64, double *left64, double *right64) {
 // The reference's f2py modules are stateless; so are these entry points for the caller.  Inside, the last solver
 // handle is kept and reused while the array shapes stay the same (a time loop calls with identical shapes every
 // step): no hipMalloc / hipFree per call, only the PCIe transfers the host-array interface implies.
-// pcl_layer1_release() frees it (also done when the library is unloaded).
+// pcl_layer1_release() frees it.
 namespace {
+// No destructor: at process exit the HIP runtime may already be torn down when static destructors of this library run
+// (it registers its own teardown lazily, i.e. AFTER this library was loaded), so the handle is released explicitly --
+// pcl_layer1_release(), which pyclaw_amd._lib registers with atexit -- or left to the process teardown.
 struct Layer1Cache {
     pcl_solver *s = nullptr;
-    ~Layer1Cache() { if (s) pcl_destroy(s); }
 };
 Layer1Cache g_l1;
+// the f2py-shaped calls share that one handle: one caller at a time (the reference's f2py modules hold the GIL and
+// module-level work arrays the same way)
+std::mutex g_l1_mutex;
 
 bool same_shape(const pcl_config &a, const pcl_config &b) {
     return a.ndim == b.ndim && a.n[0] == b.n[0] && a.n[1] == b.n[1] && a.n[2] == b.n[2] && a.mbc == b.mbc &&
@@ -1514,12 +1528,18 @@ int layer1_handle(const pcl_config &c, pcl_solver **out) {
 
 int pcl_layer1_math(int math) {
     if (math != PCL_MATH_EXACT && math != PCL_MATH_FAST && math != PCL_MATH_STRICT) return fail(PCL_EINVAL, "unknown math mode");
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
     g_l1_math = math;
     return PCL_OK;
 }
 
-void pcl_layer1_release(void) {
+static void layer1_release_locked() {
     if (g_l1.s) { pcl_destroy(g_l1.s); g_l1.s = nullptr; }
+}
+
+void pcl_layer1_release(void) {
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
+    layer1_release_locked();
 }
 
 static int host_sweep(int ndim, int rp, const double *rp_params, int fwave, int meqn, int mwaves,
@@ -1527,6 +1547,7 @@ static int host_sweep(int ndim, int rp, const double *rp_params, int fwave, int 
                       const double *aux, double dx, double dy, double dt, const int *method,
                       const int *mthlim, double *cfl, int ids, bool unsplit) {
     if (!qold || !qnew || !method || !mthlim || !cfl) return fail(PCL_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
     pcl_config c;
     memset(&c, 0, sizeof(c));
     c.ndim = ndim; c.n[0] = mx; c.n[1] = my; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves;
@@ -1552,7 +1573,7 @@ static int host_sweep(int ndim, int rp, const double *rp_params, int fwave, int 
     if (!rc && c.maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
     if (!rc) rc = unsplit ? pcl_step_hyperbolic(s, dt, cfl) : pcl_sweep(s, ids, dt, cfl);
     if (!rc) rc = pcl_get_q(s, qnew, 1);
-    if (rc) pcl_layer1_release();      // never keep a handle that failed
+    if (rc) layer1_release_locked();      // never keep a handle that failed
     return rc;
 }
 
@@ -1592,6 +1613,7 @@ int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux,
     if (!qold || !qnew || !method || !mthlim || !cfl) return fail(PCL_EINVAL, "null argument");
     if (idir < 1 || idir > 3) return fail(PCL_EINVAL, "idir must be 1, 2 or 3");
     if (mwaves < 1 || mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
     pcl_config c;
     memset(&c, 0, sizeof(c));
     c.ndim = 3; c.n[0] = mx; c.n[1] = my; c.n[2] = mz; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves;
@@ -1607,7 +1629,7 @@ int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux,
     if (!rc && maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
     if (!rc) rc = pcl_sweep(s, idir, dt, cfl);
     if (!rc) rc = pcl_get_q(s, qnew, 1);
-    if (rc) pcl_layer1_release();
+    if (rc) layer1_release_locked();
     return rc;
 }
 
@@ -1616,6 +1638,7 @@ static int g_sharp_mthlim[PCL_MAX_WAVES] = {1, 1, 1, 1, 1, 1, 1, 1};
 
 int pcl_sharp_module_mthlim(const int *mthlim, int n) {
     if (!mthlim || n < 0 || n > PCL_MAX_WAVES) return fail(PCL_EINVAL, "pcl_sharp_module_mthlim: 0 <= n <= PCL_MAX_WAVES");
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
     for (int k = 0; k < PCL_MAX_WAVES; k++) g_sharp_mthlim[k] = k < n ? mthlim[k] : 1;
     return PCL_OK;
 }
@@ -1626,6 +1649,7 @@ int pcl_step3(int rp, const double *rp_params, int meqn, int mwaves, int maux, i
     if (!qold || !qnew || !method || !mthlim || !cfl) return fail(PCL_EINVAL, "null argument");
     if (method[2] < 0) return fail(PCL_EINVAL, "step3 needs method[2] >= 0 (unsplit)");
     if (mwaves < 1 || mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
     pcl_config c;
     memset(&c, 0, sizeof(c));
     c.ndim = 3; c.n[0] = mx; c.n[1] = my; c.n[2] = mz; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves;
@@ -1641,7 +1665,7 @@ int pcl_step3(int rp, const double *rp_params, int meqn, int mwaves, int maux, i
     if (!rc && maux > 0) rc = aux ? pcl_put_aux(s, aux) : fail(PCL_EINVAL, "aux missing");
     if (!rc) rc = pcl_step_hyperbolic(s, dt, cfl);
     if (!rc) rc = pcl_get_q(s, qnew, 1);
-    if (rc) pcl_layer1_release();
+    if (rc) layer1_release_locked();
     return rc;
 }
 
@@ -1649,6 +1673,7 @@ static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, i
                       int mcapa, int mbc, int mx, int my, const double *q, double *dq, const double *aux,
                       double dx, double dy, double dt, double *cfl) {
     if (!q || !dq || !cfl) return fail(PCL_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
     pcl_config c;
     memset(&c, 0, sizeof(c));
     c.ndim = ndim; c.n[0] = mx; c.n[1] = my; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves; c.maux = maux;
@@ -1665,7 +1690,7 @@ static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, i
     if (!rc) rc = pcl_select(s, PCL_REG_DQ);
     if (!rc) rc = pcl_get_q(s, dq, 1);
     if (!rc) rc = pcl_select(s, PCL_REG_Q);
-    if (rc) pcl_layer1_release();
+    if (rc) layer1_release_locked();
     return rc;
 }
 

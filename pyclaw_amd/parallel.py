@@ -18,8 +18,9 @@ this module only does the host-side control plane:
   /opt/rocm's copy, not to a wheel's bundled one.
 
 Rendezvous: rank 0 listens on an ephemeral port and publishes ``host:port`` in a small file whose name is
-derived from ``MASTER_ADDR``/``MASTER_PORT`` (+ ``TORCHELASTIC_RUN_ID``) under ``PCL_RDZV_DIR`` (default
-``/tmp``: ranks of one node, which is what the benchmark contract launches).  The launcher's own port is
+derived from ``MASTER_ADDR``/``MASTER_PORT`` (+ ``TORCHELASTIC_RUN_ID``) under ``PCL_RDZV_DIR`` (default: a
+per-user 0700 directory, ``$XDG_RUNTIME_DIR`` or ``/tmp/pyclaw_amd-<uid>``: ranks of one node, which is what the
+benchmark contract launches; the file is created O_EXCL|O_NOFOLLOW and readers reject one owned by another uid).  The launcher's own port is
 never bound here -- ``torch.distributed.run`` keeps its agent store on it.  For several nodes either point
 ``PCL_RDZV_DIR`` at a shared directory or set ``PCL_RDZV_ADDR=host:port`` (rank 0 binds exactly that).
 """
@@ -39,6 +40,29 @@ _state = {"rank": 0, "size": 1, "initialized": False, "group": None}
 
 _MAGIC = "pyclaw_amd-rdzv-1"
 _TIMEOUT = float(os.environ.get("PCL_RDZV_TIMEOUT", "300"))
+
+
+def _rdzv_dir():
+    """Directory of the rendezvous file: PCL_RDZV_DIR if set (a shared directory for several nodes), else a per-user
+    directory nobody else can write to -- $XDG_RUNTIME_DIR, or /tmp/pyclaw_amd-<uid> created 0700 and checked to be ours
+    (a world-writable /tmp would let another user of the node plant or symlink the file)."""
+    d = os.environ.get("PCL_RDZV_DIR")
+    if d:
+        return d
+    d = os.environ.get("XDG_RUNTIME_DIR")
+    if d and os.path.isdir(d) and os.access(d, os.W_OK):
+        return d
+    d = os.path.join("/tmp", "pyclaw_amd-%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("pyclaw_amd.parallel: %s must be a directory owned by uid %d with mode 0700 "
+                           "(or set PCL_RDZV_DIR)" % (d, os.getuid()))
+    return d
 
 
 def _send(sock, obj):
@@ -78,7 +102,7 @@ class _Group(object):
             tag = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
                                 os.environ.get("TORCHELASTIC_RUN_ID", "none"))
             tag = "".join(c if c.isalnum() or c in "._-" else "_" for c in tag)
-            self.addr_file = os.path.join(os.environ.get("PCL_RDZV_DIR", "/tmp"), "pyclaw_amd_rdzv_%s.addr" % tag)
+            self.addr_file = os.path.join(_rdzv_dir(), "pyclaw_amd_rdzv_%s.addr" % tag)
         if rank == 0:
             self._serve(host, port, explicit is not None)
         else:
@@ -95,7 +119,13 @@ class _Group(object):
         port = srv.getsockname()[1]
         if not explicit:
             tmp = self.addr_file + ".%d" % os.getpid()
-            with open(tmp, "w") as f:
+            try:
+                os.unlink(tmp)                   # a leftover of a dead process with the same pid
+            except OSError:
+                pass
+            # never through a symlink, never onto an existing file
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "w") as f:
                 f.write("%s:%d:%d" % (host, port, os.getpid()))
             os.replace(tmp, self.addr_file)      # atomic: a reader never sees a partial file
             atexit.register(self._unlink)
@@ -123,7 +153,11 @@ class _Group(object):
         while time.time() < deadline:
             try:
                 if not explicit:
-                    with open(self.addr_file) as f:
+                    fd = os.open(self.addr_file, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+                    with os.fdopen(fd) as f:
+                        st = os.fstat(f.fileno())
+                        if st.st_uid != os.getuid():       # somebody else's file: not this job's rank 0
+                            raise ValueError("rendezvous file %s is owned by uid %d" % (self.addr_file, st.st_uid))
                         h, p, _pid = f.read().strip().split(":")
                     host, port = h, int(p)
                 sock = socket.create_connection((host, port), timeout=5.0)

@@ -9,6 +9,7 @@ under /root/reference, oracle/Makefile) for the paths the reference ships no gol
   ref_step2_unsplit_capa.npz  step2.f with a capacity function (mcapa = 2), method(3) = 0, 1, 2
   ref_sharp_tvd2.npz       SharpClaw flux2.f90 with lim_type 1 (tvd2), mthlim 1..5
   ref_sharp_weno_orders.npz  SharpClaw flux2.f90 with lim_type 2 and weno_order 7, 9, ..., 17 (weno.f90)
+  ref_flux2fw.npz          flux2fw.f (the classic2fw link of step2ds.f / step2.f): dim-split x / y, unsplit trans 0/1/2
   ref_sphere_setup.npz     the shallow-sphere app's own setaux.f / qinit.f / src2.f / qcor.f (40 x 20 grid)
 
 Only inputs' SEEDS and the outputs are stored (inputs are regenerated from the seed by the tests).  Run in the
@@ -102,6 +103,28 @@ def main():
         out["q_trans%d" % trans] = qn
         out["cfl_trans%d" % trans] = cfl
     np.savez_compressed(os.path.join(HERE, "ref_step2_unsplit_capa.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
+
+    # the f-wave form of the correction terms (flux2fw.f:145-152: dsign(1,s) in place of |s|), linked with the vendored
+    # Euler solver: pins the ARITHMETIC of flux2fw.f (the Euler solver returns waves, so the numbers are no physics)
+    reffw = O.RefEuler2D(fwave=True)
+    out = {}
+    method = np.array([1, 2, -1, 0, 0, 0, 0], dtype=np.int32)
+    for ids in (1, 2):
+        q0 = euler_state(70 + ids, shape)
+        qn = q0.copy("F")
+        _, cfl = reffw.step2ds(O.RP_EULER5_2D, PAR, max(mx, my), mbc, mx, my, q0.copy("F"), qn, None, dx, dy, dt, method,
+                               MTH, ids, fwave=True)
+        out["q_ids%d" % ids] = qn
+        out["cfl_ids%d" % ids] = cfl
+    for trans in (0, 1, 2):
+        q0 = euler_state(80 + trans, shape)
+        qn = q0.copy("F")
+        method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
+        _, cfl = reffw.step2(O.RP_EULER5_2D, PAR, max(mx, my), mbc, mx, my, q0.copy("F"), qn, None, dx, dy, dt, method, MTH,
+                             fwave=True)
+        out["q_trans%d" % trans] = qn
+        out["cfl_trans%d" % trans] = cfl
+    np.savez_compressed(os.path.join(HERE, "ref_flux2fw.npz"), mx=mx, my=my, dx=dx, dy=dy, dt=dt, **out)
 
     # shallow water on the sphere: the app's own data generators and source / correction terms
     sp = O.RefSphereProblem()

@@ -33,6 +33,16 @@ def run_case(case):
         aux = co.sphere_setaux(2, mx, my, -3.0, -1.0, 4.0 / mx, 2.0 / my)
         q0 = co.sphere_qinit(2, mx, my, -3.0, -1.0, 4.0 / mx, 2.0 / my)[:, 2:-2, 2:-2]
         return S.shallow_sphere(pyclaw, mx, my, tfinal=2.0, nout=2, aux_full=aux, q0=q0)
+    if case == "sphere_sharpclaw":
+        # C5 as BASELINE configures it: SharpClaw WENO5 + SSP104 on the sphere (mbc = 3): every Runge-Kutta stage
+        # exchanges its halo and mirrors the pole rows (shallow_4_Rossby_Haurwitz_wave.py:295-313) on the edge blocks
+        from apps import shallow_sphere as S
+        from oracle import oracle as O
+        co = O.COracle()
+        mx, my = 48, 24
+        aux = co.sphere_setaux(3, mx, my, -3.0, -1.0, 4.0 / mx, 2.0 / my)
+        q0 = co.sphere_qinit(3, mx, my, -3.0, -1.0, 4.0 / mx, 2.0 / my)[:, 3:-3, 3:-3]
+        return S.shallow_sphere(pyclaw, mx, my, tfinal=0.5, nout=1, aux_full=aux, q0=q0, solver_type='sharpclaw')
     if case == "shockbubble_ds":
         claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=True)
     elif case == "shockbubble_unsplit":
@@ -45,6 +55,10 @@ def run_case(case):
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.06, nout=2)
     elif case == "acoustics_unsplit":
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.06, nout=2, dim_split=0)
+    elif case == "acoustics_ds_mbc3":        # three ghost layers: the outer layer is copied through next to the exchange
+        claw = problems.acoustics2D(pyclaw, mx=1000, my=40, tfinal=0.03, nout=1, run=False)
+        claw.solver.mbc = 3
+        claw.run()
     elif case == "acoustics_sharp":
         claw = problems.acoustics2D(pyclaw, mx=90, my=80, tfinal=0.03, nout=1, solver_type='sharpclaw')
     elif case == "acoustics_sharp9":
@@ -69,6 +83,10 @@ def oracle_case(case):
         p = D.shallow_sphere_problem(co)
         D.run(p, co, 2.0, 2)
         return p.q, p
+    if case == "sphere_sharpclaw":
+        p = D.shallow_sphere_problem(co, mx=48, my=24, solver_type='sharpclaw')
+        D.run(p, co, 0.5, 1)
+        return p.q, p
     if case.startswith("shockbubble"):
         p = D.shockbubble_problem(mx=160, my=40, dim_split=not case.endswith("_unsplit"))
         D.run(p, co, 0.03, 1)
@@ -81,6 +99,9 @@ def oracle_case(case):
     elif case == "acoustics_odd":
         p = D.acoustics2d_problem(mx=91, my=83, dim_split=False, order_trans=1)
         D.run(p, co, 0.06, 2)
+    elif case == "acoustics_ds_mbc3":
+        p = D.acoustics2d_problem(mx=1000, my=40, dim_split=True, order_trans=1, mbc=3)
+        D.run(p, co, 0.03, 1)
     elif case == "acoustics3d_ds":
         p = D.acoustics3d_problem('hom', mx=40, my=18, mz=14)
         D.run(p, co, 0.3, 1)

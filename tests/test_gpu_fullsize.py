@@ -62,10 +62,10 @@ def windows(rng, shape, w, pad, count):
         yield tuple(int(rng.integers(pad, n - w - pad)) for n in shape)
 
 
-def test_c3_euler_4096_spot_parity_and_shift(coracle):
+@pytest.mark.parametrize("n", [4096, 8192])      # C3's grid and C4's global grid (8192^2: 2.7 GB per buffer)
+def test_c3_euler_4096_spot_parity_and_shift(n, coracle):
     from pyclaw_amd import _lib as L
     lib = L.lib()
-    n = 4096
     rng = np.random.default_rng(42)
     mth = [4, 4, 4, 4, 2]
     dt = 0.1 / n

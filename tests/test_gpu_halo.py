@@ -121,7 +121,9 @@ def test_step_with_comm_single_rank():
 
 
 @pytest.mark.parametrize("mx,my,overlap", [(1000, 37, 1), (482, 64, 1), (723, 9, 1), (100, 30, 1), (1000, 37, 0), (1000, 37, 2),
-                                               (481, 10, 2), (962, 11, 2)])
+                                               (481, 10, 2), (962, 11, 2),
+                                               # the block of BASELINE configs[3]'s 2 x 4 layout (8192^2 / (2 x 4))
+                                               (4096, 2048, 1), (4096, 2048, 0), (4096, 2048, 2)])
 def test_overlapped_step_equals_periodic(mx, my, overlap, monkeypatch):
     """pcl_bc_step on a block whose 8 neighbours are itself (halo exchange on its own stream, overlapped
     with the interior tiles of the x pass; rim tiles afterwards) == the same steps with local periodic
@@ -295,7 +297,7 @@ def make_unsplit_solver(L, mx, my, capa):
 
 @pytest.mark.parametrize("mx,my,overlap,capa", [(300, 47, 1, False), (300, 47, 2, False), (300, 47, 0, False),
                                                     (190, 31, 2, True), (190, 31, 1, True), (61, 13, 2, False),
-                                                    (125, 16, 2, False)])
+                                                    (125, 16, 2, False), (4096, 2048, 1, False), (4096, 2048, 2, False)])
 def test_overlapped_unsplit_step_equals_periodic(mx, my, overlap, capa, monkeypatch):
     """The unsplit step (step2.f) of a block whose 8 neighbours are itself: ghost frame built on the halo stream while
     the x phase runs the tiles that read no ghost cell, rim tiles behind it, y phase after the join == the same steps

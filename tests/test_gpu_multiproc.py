@@ -57,12 +57,14 @@ def launch(case, nranks, overlap=None):
                                          ("rotating_classic", 4), ("rotating_classic", 2), ("rotating_sharpclaw", 4),
                                          ("acoustics_sharp9", 4), ("shockbubble_pycb", 2), ("shockbubble_pycb", 4),
                                          ("sphere_classic", 2), ("sphere_classic", 4),
-                                         ("acoustics_odd", 5), ("acoustics_odd", 3), ("acoustics_odd", 4)])
+                                         ("sphere_sharpclaw", 2), ("sphere_sharpclaw", 4),
+                                         ("acoustics_odd", 5), ("acoustics_odd", 3), ("acoustics_odd", 4),
+                                         ("acoustics_ds_mbc3", 2), ("acoustics_ds_mbc3", 4)])
 def test_decomposed_device_run_equals_serial(case, nranks):
     launch(case, nranks)
 
 
-@pytest.mark.parametrize("case", ["acoustics_ds", "acoustics_unsplit", "acoustics_sharp"])
+@pytest.mark.parametrize("case", ["acoustics_ds", "acoustics_unsplit", "acoustics_sharp", "sphere_sharpclaw"])
 def test_decomposed_device_run_sequential_exchange(case):
     """PCL_HALO_OVERLAP=0: the exchange in front of the step on one stream"""
     launch(case, 4, overlap=0)

@@ -119,3 +119,34 @@ def test_sharpclaw_flux2_matches_reference(coracle, mx, my, lim):
     inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
     # a strong random state makes WENO overshoot into negative pressure at some edges: NaNs, in the same places
     assert np.array_equal(a[inner], b[inner], equal_nan=True) and ca == cb
+
+
+@pytest.mark.skipif(not O.RefEuler2D.available(fwave=True), reason="oracle/_ref/libref_euler2d_fw.so not built")
+@pytest.mark.parametrize("mx,my", [(7, 5), (41, 30)])
+@pytest.mark.parametrize("strong", [False, True])
+@pytest.mark.parametrize("mth", [[4, 4, 4, 4, 2], [1, 2, 3, 5, 0]])
+def test_fwave_form_matches_reference_flux2fw(coracle, mx, my, strong, mth):
+    """the oracle's fwave=1 path against the reference's classic2fw link (flux2fw.f), dim-split and unsplit, on random
+    Euler states: flux2fw.f:145-152 bit for bit"""
+    reffw = O.RefEuler2D(fwave=True)
+    rng = np.random.default_rng(3 * mx + my)
+    mbc = 2
+    q0 = euler_state(rng, (mx + 2 * mbc, my + 2 * mbc), strong)
+    par = [1.4, 0.4]
+    dx, dy, dt = 1.0 / mx, 1.0 / my, 0.05 / max(mx, my)
+    method = np.array([1, 2, -1, 0, 0, 0, 0], dtype=np.int32)
+    for ids in (1, 2):
+        a, b = q0.copy("F"), q0.copy("F")
+        _, ca = coracle.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), a, None, dx, dy, dt, method,
+                                mth, ids, fwave=True)
+        _, cb = reffw.step2ds(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), b, None, dx, dy, dt, method,
+                              mth, ids, fwave=True)
+        assert np.array_equal(a, b) and ca == cb
+    for trans in (0, 1, 2):
+        method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
+        a, b = q0.copy("F"), q0.copy("F")
+        _, ca = coracle.step2(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), a, None, dx, dy, dt, method, mth,
+                              fwave=True)
+        _, cb = reffw.step2(O.RP_EULER5_2D, par, max(mx, my), mbc, mx, my, q0.copy("F"), b, None, dx, dy, dt, method, mth,
+                            fwave=True)
+        assert np.array_equal(a, b) and ca == cb

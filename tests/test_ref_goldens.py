@@ -74,6 +74,36 @@ def test_oracle_step2_unsplit_capa(coracle, trans):
     assert np.array_equal(qn, z["q_trans%d" % trans]) and cfl == float(z["cfl_trans%d" % trans])
 
 
+@pytest.mark.parametrize("which", ["ids1", "ids2", "trans0", "trans1", "trans2"])
+def test_oracle_flux2fw_form(coracle, which):
+    """flux2fw.f (classic2fw: step2ds.f / step2.f linked with flux2fw.f) built from the reference tree with the vendored
+    Euler rpn2/rpt2: the oracle's fwave=1 path must reproduce the reference's own bits.  This pins the ARITHMETIC of
+    flux2fw.f:145-152 (dsign(1,s) in the correction); the HIP f-wave kernels are held to the oracle by
+    tests/test_fwave.py.  (step1fw.f stays unpinned by a reference build: no rp1 lies in the reference tree.)"""
+    z = load("ref_flux2fw.npz")
+    mx, my, shape, dx, dy, dt = shapes(z, 2)
+    if which.startswith("ids"):
+        ids = int(which[3:])
+        q0 = G.euler_state(70 + ids, shape)
+        qn = q0.copy("F")
+        method = np.array([1, 2, -1, 0, 0, 0, 0], dtype=np.int32)
+        _, cfl = coracle.step2ds(O.RP_EULER5_2D, G.PAR, max(mx, my), 2, mx, my, q0.copy("F"), qn, None, dx, dy, dt, method,
+                                 G.MTH, ids, fwave=True)
+        plain = q0.copy("F")
+        coracle.step2ds(O.RP_EULER5_2D, G.PAR, max(mx, my), 2, mx, my, q0.copy("F"), plain, None, dx, dy, dt, method, G.MTH, ids)
+    else:
+        trans = int(which[5:])
+        q0 = G.euler_state(80 + trans, shape)
+        qn = q0.copy("F")
+        method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
+        _, cfl = coracle.step2(O.RP_EULER5_2D, G.PAR, max(mx, my), 2, mx, my, q0.copy("F"), qn, None, dx, dy, dt, method,
+                               G.MTH, fwave=True)
+        plain = q0.copy("F")
+        coracle.step2(O.RP_EULER5_2D, G.PAR, max(mx, my), 2, mx, my, q0.copy("F"), plain, None, dx, dy, dt, method, G.MTH)
+    assert np.array_equal(qn, z["q_" + which]) and cfl == float(z["cfl_" + which])
+    assert not np.array_equal(qn, plain)          # the f-wave form really is a different formula
+
+
 @pytest.mark.parametrize("mth", [1, 2, 3, 4, 5])
 def test_oracle_sharp_tvd2(coracle, mth):
     """lim_type = 1 (tvd2, reconstruct.f90:568-625).  Cells of the first interior row / column are left out: there the
@@ -120,7 +150,7 @@ def test_hip_step2_unsplit_capa(trans):
     method = np.array([1, 2, trans, 0, 0, 2, 2], dtype=np.int32)
     mth = np.array(G.MTH, dtype=np.int32)
     cfl = C.c_double()
-    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(np.array(G.PAR)), 0, 5, 5, 2, 2, mx, my, L.d(q0), L.d(out), L.d(aux),
+    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(np.array(G.PAR + [0.0] * 6)), 0, 5, 5, 2, 2, mx, my, L.d(q0), L.d(out), L.d(aux),
                               dx, dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
     inner = (slice(None), slice(2, -2), slice(2, -2))
     assert np.array_equal(out[inner], z["q_trans%d" % trans][inner]) and cfl.value == float(z["cfl_trans%d" % trans])
@@ -137,7 +167,7 @@ def test_hip_step2_unsplit(trans):
     method = np.array([1, 2, trans, 0, 0, 0, 0], dtype=np.int32)
     mth = np.array(G.MTH, dtype=np.int32)
     cfl = C.c_double()
-    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(np.array(G.PAR)), 0, 5, 5, 0, 2, mx, my, L.d(q0), L.d(out), None,
+    L.check(L.lib().pcl_step2(O.RP_EULER5_2D, L.d(np.array(G.PAR + [0.0] * 6)), 0, 5, 5, 0, 2, mx, my, L.d(q0), L.d(out), None,
                               dx, dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp)))
     inner = (slice(None), slice(2, -2), slice(2, -2))
     assert np.array_equal(out[inner], z["q_trans%d" % trans][inner]) and cfl.value == float(z["cfl_trans%d" % trans])
@@ -154,7 +184,7 @@ def test_hip_step2ds_capa(ids):
     method = np.array([1, 2, -1, 0, 0, 2, 2], dtype=np.int32)
     mth = np.array(G.MTH, dtype=np.int32)
     cfl = C.c_double()
-    L.check(L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(np.array(G.PAR)), 0, 5, 5, 2, 2, mx, my, L.d(q0), L.d(out),
+    L.check(L.lib().pcl_step2ds(O.RP_EULER5_2D, L.d(np.array(G.PAR + [0.0] * 6)), 0, 5, 5, 2, 2, mx, my, L.d(q0), L.d(out),
                                 L.d(aux), dx, dy, dt, L.i(method), L.i(mth), C.cast(C.byref(cfl), L.dp), ids))
     assert np.array_equal(out, z["q_ids%d" % ids]) and cfl.value == float(z["cfl_ids%d" % ids])
 
