@@ -304,7 +304,9 @@ int drain_timing(pcl_solver *s) {
 // corner cell is the y rule applied to an x-ghost cell) written as an index remap, like the dim-split x pass does
 // while loading its tiles -- and is copied to dst (the y phase updates t1 in place and its ghost frame must equal
 // qold's).  bc[k] < 0: no fill on that side (neighbour block or a fill done elsewhere); 100 = constant state.
-struct FrameBc { int t[4]; double c[4][8]; };
+// only: 0 = every ghost cell; 1 / 2 = only the ghost columns / rows beyond the two layers the sweep tiles hold (mbc > 2:
+// the cells no tile of an x / y pass writes, so the copy may run beside the tiles)
+struct FrameBc { int t[4]; double c[4][8]; int only; };
 static inline unsigned frame_blocks(const pcl_solver *s) {      // one thread per ghost cell, at most 256 workgroups
     const long n = s->J > 2 * s->cfg.mbc ? 2L * s->cfg.mbc * (s->I + s->J - 2 * s->cfg.mbc) : (long)s->I * s->J;
     const long b = (n + 255) / 256;
@@ -337,6 +339,8 @@ __global__ void frame_kernel(double *q, double *dst, int nm, int I, int J, int m
         else if (t < nfull) { const int r = (int)(t / I); i = (int)(t % I); j = r < mbc ? r : J - 2 * mbc + r; }
         else { const long u = t - nfull; const int c = (int)(u % (2 * mbc)); j = mbc + (int)(u / (2 * mbc)); i = c < mbc ? c : I - 2 * mbc + c; }
         if (i >= mbc && i < I - mbc && j >= mbc && j < J - mbc) continue;
+        if (f.only == 1 && i >= mbc - 2 && i < I - (mbc - 2)) continue;
+        if (f.only == 2 && j >= mbc - 2 && j < J - (mbc - 2)) continue;
         int si, sj, sdi, sdj;
         bool ni, nj, ci, cj;
         // y first (the side applied LAST): the sphere app's pole boundary also reverses the row over its whole ghosted
@@ -375,10 +379,18 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
     if (s->cfg.mbc > 2 && s->cfg.ndim <= 2 && sub != 1) {
         // more than two ghost layers: the sweep kernels copy through the two layers their strips hold; the outer
         // layers of qnew are copies of qold as well (step2ds.f / step1.f update interior cells of a copy).
-        // In an overlapped decomposed step the copy goes with the RIM launch (sub == 2), i.e. behind the halo exchange
-        // on its stream: the interior launch (sub == 1) runs while the unpack writes those very ghost cells of qin.
+        // Only the layers no tile of this pass writes are copied (x pass: outer ghost columns of every row, y pass: outer
+        // ghost rows), with the pass' own boundary conditions where it evaluates them while loading (a.vbc_on: those
+        // ghost cells were never filled in memory).  In an overlapped decomposed step the copy goes with the RIM
+        // launch (sub == 2), i.e. behind the halo exchange on its stream: the interior launch (sub == 1) runs while the
+        // unpack writes those very ghost cells of qin.
         FrameBc f;
-        for (int k = 0; k < 4; k++) { f.t[k] = -1; for (int m = 0; m < 8; m++) f.c[k][m] = 0.0; }
+        for (int k = 0; k < 4; k++) {
+            const int t = a.vbc_on ? a.vbc[k] : -1;
+            f.t[k] = t == PCL_BC_CUSTOM ? 100 : t;
+            for (int m = 0; m < 8; m++) f.c[k][m] = a.vbc_on ? a.vconst[k][m] : 0.0;
+        }
+        f.only = ids;
         hipLaunchKernelGGL(frame_kernel, dim3(frame_blocks(s)), dim3(256), 0, stream, const_cast<double *>(qin), qout,
                            s->cfg.meqn, s->I, s->J, s->cfg.mbc, s->pitch, s->plane, f);
         HIP_TRY(hipGetLastError());
@@ -496,6 +508,7 @@ int do_unsplit3(pcl_solver *s, double dt) {
 
 static int unsplit_frame(pcl_solver *s, hipStream_t stream, const int *bc = nullptr, const double *cstate = nullptr) {
     FrameBc f;
+    f.only = 0;
     for (int k = 0; k < 4; k++) {
         f.t[k] = bc ? (bc[k] == PCL_BC_CUSTOM ? 100 : bc[k]) : -1;
         for (int m = 0; m < 8; m++) f.c[k][m] = (bc && bc[k] == PCL_BC_CUSTOM && cstate) ? cstate[k * PCL_MAX_RP_PARAMS + m] : 0.0;
@@ -1280,6 +1293,7 @@ static int sharp_frame(pcl_solver *s, const int *bc, const double *cstate, hipSt
         return fail(PCL_ECOMM, err);
     if (s->cfg.ndim == 2) {       // all four sides in one launch (the index-remap composition of frame_kernel)
         FrameBc f;
+        f.only = 0;
         for (int k = 0; k < 4; k++) {
             f.t[k] = bc[k] == PCL_BC_CUSTOM ? 100 : bc[k];
             for (int m = 0; m < 8; m++) f.c[k][m] = (bc[k] == PCL_BC_CUSTOM && cstate) ? cstate[k * PCL_MAX_RP_PARAMS + m] : 0.0;

@@ -30,7 +30,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-GAMMA, GAMMA1 = 1.4, 0.4
+GAMMA = 1.4
+GAMMA1 = GAMMA - 1.0          # 0.39999999999999991: the reference scripts compute it (test/euler/2d/shockbubble.py:7-8)
 
 CASES = {
     #  name         (nx,   ny,   proc grid, steps)
