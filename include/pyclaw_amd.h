@@ -330,6 +330,17 @@ int pcl_step_count(pcl_solver *s, long *steps);
 int pcl_comm_unique_id(char uid[128]);
 int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128],
                   const int neighbors[8]);
+/* Exchange-ahead for the overlapped dimension-split 2-D step (pcl_bc_step): with on = 1 the halo exchange of the NEW
+ * state is enqueued on the halo stream right behind the y pass that produced it -- it travels while the Courant number
+ * is handed over, the host decides accept / retake and the next x pass starts its interior tiles -- and the next
+ * pcl_bc_step skips its own exchange when nothing has touched the state in between (any other call that changes q
+ * or its ghost cells makes it exchange again; a rejected step goes back to the pre-step buffer, whose ghost frame is
+ * still filled).  petclaw has no counterpart (globalToLocal is blocking, petclaw/state.py:254-262).  EVERY rank of
+ * the communicator must make the same choice (the order of operations on the communicator depends on it):
+ * pcl_halo_can_overlap tells whether this rank's block qualifies (decomposed, dim-split 2-D, interior x-pass tiles,
+ * PCL_HALO_OVERLAP=1); the caller agrees over all ranks (pyclaw_amd/clawpack.py) and then switches it on everywhere. */
+int pcl_halo_can_overlap(pcl_solver *s, int *yes);
+int pcl_halo_exchange_ahead(pcl_solver *s, int on);
 /* The same decomposed device path with a host-staged wire instead of RCCL (diagnostics, and multi-process tests on
  * ONE device: RCCL refuses two ranks per GPU).  Packed strips go to pinned host memory, `xfn` carries them between
  * the processes, the received strips go back up; the CFL maximum goes through `rfn`.  send/recv: all 8 directions'

@@ -106,6 +106,8 @@ PROTOTYPES = {
     "pcl_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, ip]),
     "pcl_comm_check": (C.c_int, [C.c_int, C.c_int, ip]),
     "pcl_comm_init_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ip, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcl_halo_can_overlap": (C.c_int, [C.c_void_p, ip]),
+    "pcl_halo_exchange_ahead": (C.c_int, [C.c_void_p, C.c_int]),
     "pcl_halo_exchange": (C.c_int, [C.c_void_p]),
     "pcl_halo_exchange_aux": (C.c_int, [C.c_void_p]),
     "pcl_allreduce_max": (C.c_int, [C.c_void_p, dp]),

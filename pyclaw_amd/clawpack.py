@@ -243,6 +243,28 @@ class ClawSolver(Solver):
         self._rp_id = rp.id
         self._src_fused = False          # a fresh device handle
         self._decide_src_fusion(state)
+        self._decide_exchange_ahead(state)
+
+    def _decide_exchange_ahead(self, state):
+        """Decomposed dimension-split 2-D runs: let the library send the new state's halo right behind the y pass
+        (pcl_halo_exchange_ahead) when nothing between two steps touches q -- no start_step, no Strang half step, a
+        source term only if it is fused into the y pass, every boundary condition a device one -- and EVERY rank's
+        block qualifies (the ranks agree here: the order of operations on the communicator depends on the choice).
+        PCL_EXCHANGE_AHEAD=0 switches it off."""
+        import ctypes
+        import os
+        from . import parallel
+        self.exchange_ahead = False
+        if not self._halo_active:
+            return
+        yes = ctypes.c_int(0)
+        _lib.check(_lib.lib().pcl_halo_can_overlap(self._h, ctypes.byref(yes)))
+        mine = (bool(yes.value) and os.environ.get("PCL_EXCHANGE_AHEAD", "1") != "0"
+                and not self._pre_step_modifies_q() and (self.step_src is None or self._src_fused)
+                and self._device_bc_spec(state) is not None and not state.grid.gauges)
+        if all(parallel.allgather(bool(mine))):
+            _lib.check(_lib.lib().pcl_halo_exchange_ahead(self._h, 1))
+            self.exchange_ahead = True
 
     def _decide_src_fusion(self, state):
         """Godunov-split device source of the 2-D Euler step: applied by the y pass / y phase while it stores its

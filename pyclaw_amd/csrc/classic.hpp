@@ -531,9 +531,12 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_acro
     // offsets), so every pair is aligned; x tiles keep the pair together in LDS (ds_write_b128), y tiles split it
     // (their LDS rows have the odd pitch 17).
     const bool full_tile = a0 + T::ALONG <= n_along && b0 >= 0 && b0 + T::ACROSS <= n_across && (a.mbc & 1) == 0;
+    // a tile takes the remap path only where it touches a side whose boundary condition is evaluated here: next to a
+    // neighbour block (vbc < 0) the ghost cells are real memory (the halo exchange filled them) and the tile loads
+    // like an interior one -- the rim tiles of a decomposed block keep the 16-byte loads
     const bool vbc_tile = IXY == 1 && a.vbc_on &&
-                          (a0 < a.mbc || a0 + T::ALONG > n_along - a.mbc || b0 < a.mbc ||
-                           b0 + T::ACROSS > n_across - a.mbc || DIM1);
+                          (DIM1 || (a0 < a.mbc && a.vbc[0] >= 0) || (a0 + T::ALONG > n_along - a.mbc && a.vbc[1] >= 0) ||
+                           (b0 < a.mbc && a.vbc[2] >= 0) || (b0 + T::ACROSS > n_across - a.mbc && a.vbc[3] >= 0));
     if (IXY == 1 && full_tile && !vbc_tile) {
         constexpr int PAIRS = T::ALONG / 2, SLOTS = PAIRS * T::ACROSS;      // 122 pairs x 4 rows
 #pragma unroll

@@ -73,6 +73,18 @@ struct pcl_solver {
     hipStream_t hstream = nullptr;
     hipEvent_t ev_h0 = nullptr, ev_h1 = nullptr;
     int overlap = 1;
+    // Exchange-ahead (pcl_halo_exchange_ahead): the halo exchange of the NEW state is enqueued on the halo stream
+    // right behind the y pass that produced it, so it runs through the hand-over of the Courant number, the host's
+    // accept / retake decision and the first tiles of the next x pass instead of in front of that pass' rim tiles.
+    // ghost_ok[] names the buffers whose ghost frame such an exchange (or the one at the start of a step) has filled
+    // and nothing has touched since: the state itself and, for a retaken step, the pre-step state (pcl_undo_step).
+    int exchange_ahead = 0;
+    hipEvent_t ev_y = nullptr;
+    const double *ghost_ok[2] = {nullptr, nullptr};
+    bool ghosts_filled(const double *buf) const { return buf && (ghost_ok[0] == buf || ghost_ok[1] == buf); }
+    void ghosts_mark(const double *buf) { if (!ghosts_filled(buf)) { ghost_ok[1] = ghost_ok[0]; ghost_ok[0] = buf; } }
+    void ghosts_drop(const double *buf) { for (auto &g : ghost_ok) if (g == buf) g = nullptr; }
+    void ghosts_drop_all() { ghost_ok[0] = ghost_ok[1] = nullptr; }
 };
 
 static inline double *&cur(pcl_solver *s) { return s->sel == 0 ? s->q : s->sreg[s->sel]; }
@@ -560,12 +572,20 @@ __global__ void cfl_handover(unsigned long long *word, unsigned long long *host,
 
 // The step's Courant number: in a decomposed run the max over all blocks (petclaw/cfl.py:29-31),
 // reduced on the device before the single 8-byte read-back.
-int read_cfl(pcl_solver *s, double *cfl) {
+int read_cfl_begin(pcl_solver *s) {
     s->step_no++;           // every launch of the step / stage is enqueued: the next one decides afresh whether it is timed
     if (s->halo.active) {
         std::string err;
         if (s->halo.allreduce_max_device(reinterpret_cast<double *>(s->cfl_dev), err)) return fail(PCL_ECOMM, err);
     }
+    return PCL_OK;
+}
+int read_cfl_end(pcl_solver *s, double *cfl);
+int read_cfl(pcl_solver *s, double *cfl) {
+    if (int rc = read_cfl_begin(s)) return rc;
+    return read_cfl_end(s, cfl);
+}
+int read_cfl_end(pcl_solver *s, double *cfl) {
     if (s->cfl_poll) {
         // One single-thread kernel behind the sweeps hands the word over through host memory the device can
         // write (the value, then a sequence number with release semantics at system scope) and re-zeroes it;
@@ -763,6 +783,7 @@ void pcl_destroy(pcl_solver *s) {
     s->halo.destroy();
     if (s->ev_h0) hipEventDestroy(s->ev_h0);
     if (s->ev_h1) hipEventDestroy(s->ev_h1);
+    if (s->ev_y) hipEventDestroy(s->ev_y);
     if (s->hstream) hipStreamDestroy(s->hstream);
     for (auto &t : s->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto &e : s->evpool) hipEventDestroy(e);
@@ -800,6 +821,7 @@ static int put_array(pcl_solver *s, const double *host, double *dev, int nm, int
 }
 
 int pcl_put_q(pcl_solver *s, const double *host, int with_ghosts) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s || !host) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     s->undo_slot = nullptr;
@@ -862,6 +884,7 @@ int pcl_get_strip(pcl_solver *s, int idim, int side, int width, double *host) {
 }
 
 int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *host) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s || !host) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     int ni, nj, io, jo;
@@ -960,6 +983,7 @@ static int bc_launch(pcl_solver *s, int idim, int side, int type, const double *
 }
 
 int pcl_bc(pcl_solver *s, int idim, int side, int bctype) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (idim < 0 || idim >= s->cfg.ndim || side < 0 || side > 1) return fail(PCL_EINVAL, "bad idim/side");
     HIP_TRY(hipSetDevice(s->cfg.device));
@@ -987,6 +1011,7 @@ int pcl_bc_aux(pcl_solver *s, int idim, int side, int bctype) {
 }
 
 int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s || !state) return fail(PCL_EINVAL, "null argument");
     if (idim < 0 || idim >= s->cfg.ndim || side < 0 || side > 1) return fail(PCL_EINVAL, "bad idim/side");
     HIP_TRY(hipSetDevice(s->cfg.device));
@@ -995,6 +1020,7 @@ int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state) {
 }
 
 int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     if (ids < 1 || ids > s->cfg.ndim) return fail(PCL_EINVAL, "bad ids");
@@ -1007,6 +1033,7 @@ int pcl_sweep(pcl_solver *s, int ids, double dt, double *cfl) {
 }
 
 int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s || !cfl) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.kind != PCL_KIND_CLASSIC) return fail(PCL_ESTATE, "classic call on a SharpClaw solver");
     HIP_TRY(hipSetDevice(s->cfg.device));
@@ -1062,6 +1089,7 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     int box[4], ntiles[2];
     const bool overlapped = s->halo.active && fused && s->cfg.ndim == 2 && s->overlap && s->sel == 0 &&
                             pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, dt), box, ntiles);
+    if (!overlapped) s->ghosts_drop_all();       // exchange-ahead lives in the overlapped dimension-split step only
     if (overlapped) {
         // a side without a neighbour block gets its ghost cells from the boundary conditions the kernel evaluates
         // while loading -- nothing there waits for the exchange, so the interior box reaches that edge
@@ -1087,10 +1115,10 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             if (he == hipSuccess) he = hipStreamWaitEvent(hs, s->ev_h0, 0);
             if (he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream fork: ") + hipGetErrorString(he));
         }
+        if (!rc && ov && !seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);   // interior tiles first (see the dim-split step)
         if (!rc && s->halo.active && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, hs))
             rc = fail(PCL_ECOMM, err);
         if (!rc) rc = unsplit_frame(s, hs, bc, cstate);                // all four sides + the copy to t1: one launch
-        if (!rc && ov && !seq) rc = unsplit_phase(s, 1, dt, 1, s->stream);   // interior tiles, concurrent with the frame
         if (!rc) rc = unsplit_phase(s, 1, dt, ov ? 2 : 0, hs);        // rim tiles behind the frame (or all tiles)
         if (ov && !seq) {                                              // join, also on the error paths
             hipError_t he = hipEventRecord(s->ev_h1, hs);
@@ -1122,17 +1150,26 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             rc = do_sweep(s, s->q, s->t1, 1, dt, 1, box);
             if (!rc && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err)) rc = fail(PCL_ECOMM, err);
         } else {
-            hipError_t hf = hipEventRecord(s->ev_h0, s->stream);     // q of the previous step is complete
-            if (hf == hipSuccess) hf = hipStreamWaitEvent(s->hstream, s->ev_h0, 0);
+            // exchange-ahead: the previous step (or a retaken step's first attempt) already exchanged this buffer's
+            // halo on the halo stream; the rim tiles queue up behind it there
+            const bool have = s->exchange_ahead && s->ghosts_filled(s->q);
+            hipError_t hf = hipSuccess;
+            if (!have) {
+                hf = hipEventRecord(s->ev_h0, s->stream);             // q of the previous step is complete
+                if (hf == hipSuccess) hf = hipStreamWaitEvent(s->hstream, s->ev_h0, 0);
+            }
             if (hf != hipSuccess) {
                 s->vbc_on = 0;
                 return bail(s, fail(PCL_EHIP, std::string("halo stream fork: ") + hipGetErrorString(hf)));
             }
-            if (s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, s->hstream)) {
-                s->vbc_on = 0;
-                return bail(s, fail(PCL_ECOMM, err));
-            }
+            // The interior tiles go FIRST: the step starts on an idle device (the host has just read the previous
+            // Courant number), and the host needs some tens of microseconds to enqueue the group of Send/Recv -- with
+            // the interior launch already queued the device works through that time instead of waiting for it
             rc = do_sweep(s, s->q, s->t1, 1, dt, 1, box);      // interior tiles, concurrent with the exchange
+            if (!rc && !have) {
+                if (s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, s->hstream)) rc = fail(PCL_ECOMM, err);
+                else s->ghosts_mark(s->q);
+            }
             // rim tiles (ghost frame + physical BCs) behind the exchange on ITS stream: they start as soon as
             // the frame has arrived and fill the machine next to the interior kernel's tail
             if (!rc) rc = do_sweep(s, s->q, s->t1, 1, dt, 2, box, s->hstream);
@@ -1142,10 +1179,28 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
         }
         if (!rc && s->overlap == 2) rc = do_sweep(s, s->q, s->t1, 1, dt, 2, box);
         s->vbc_on = 0;
-        if (rc) return bail(s, rc);
-        if (int rc2 = do_sweep(s, s->t1, s->t2, 2, dt)) return bail(s, rc2);
+        if (rc) { s->ghosts_drop_all(); return bail(s, rc); }
+        s->ghosts_drop(s->t2);                       // the y pass writes that buffer, ghost rows included
+        if (int rc2 = do_sweep(s, s->t1, s->t2, 2, dt)) { s->ghosts_drop_all(); return bail(s, rc2); }
         std::swap(s->q, s->t2);
         s->undo_slot = &s->t2;
+        if (s->exchange_ahead && s->overlap == 1) {
+            // The new state's halo travels NOW, behind the y pass, on the halo stream: through the Courant number's
+            // hand-over and the host's decision.  If the step is rejected the exchange was for nothing -- the pre-step
+            // buffer comes back (pcl_undo_step) with its own ghost frame still filled.  The CFL all-reduce is
+            // enqueued FIRST (read_cfl's issue order on the communicator: all-reduce, then this group, on every rank).
+            const int rc3 = read_cfl_begin(s);
+            if (rc3) { s->ghosts_drop_all(); return rc3; }
+            hipError_t he = hipEventRecord(s->ev_y, s->stream);
+            if (he == hipSuccess) he = hipStreamWaitEvent(s->hstream, s->ev_y, 0);
+            if (he != hipSuccess) { s->ghosts_drop_all(); return bail(s, fail(PCL_EHIP, std::string("exchange-ahead fork: ") + hipGetErrorString(he))); }
+            if (s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, s->hstream)) {
+                s->ghosts_drop_all();
+                return bail(s, fail(PCL_ECOMM, err));
+            }
+            s->ghosts_mark(s->q);
+            return read_cfl_end(s, cfl);
+        }
         return read_cfl(s, cfl);
     }
     if (fused) {
@@ -1193,6 +1248,7 @@ int pcl_backup(pcl_solver *s) {
 }
 
 int pcl_restore(pcl_solver *s) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (!s->bak) return fail(PCL_ESTATE, "pcl_restore without pcl_backup");
     HIP_TRY(hipSetDevice(s->cfg.device));
@@ -1203,6 +1259,7 @@ int pcl_restore(pcl_solver *s) {
 }
 
 int pcl_src(pcl_solver *s, int src_id, double dt, const double *params, int nparams) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     if (src_id == PCL_SRC_EULER_RADIAL) {
@@ -1257,6 +1314,7 @@ int pcl_sharp_fuse_dq_src(pcl_solver *s, int src_id, const double *params, int n
 }
 
 int pcl_select(pcl_solver *s, int reg) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (reg == 0) { s->sel = 0; return PCL_OK; }
     if (s->cfg.kind != PCL_KIND_SHARPCLAW || reg < 0 || reg > 4) return fail(PCL_EINVAL, "bad register");
@@ -1343,8 +1401,8 @@ static int sharp_passes(pcl_solver *s, double dt, int rk_op, const double *ra, c
             if (he == hipSuccess) he = hipStreamWaitEvent(hs, s->ev_h0, 0);
             if (he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream fork: ") + hipGetErrorString(he));
         }
+        if (!rc && !seq) rc = sharp_pass(s, 1, dt, rk_op, ra, rb, rd, ca, cb, cc, 1, s->stream);   // interior tiles first
         if (!rc) rc = sharp_frame(s, bc, cstate, hs);
-        if (!rc && !seq) rc = sharp_pass(s, 1, dt, rk_op, ra, rb, rd, ca, cb, cc, 1, s->stream);
         if (!rc) rc = sharp_pass(s, 1, dt, rk_op, ra, rb, rd, ca, cb, cc, 2, hs);
         if (!seq) {                                                    // join, also on the error paths
             hipError_t he = hipEventRecord(s->ev_h1, hs);
@@ -1721,6 +1779,21 @@ int pcl_sharp_flux2(int rp, const double *rp_params, int lim_type, int meqn, int
 }
 
 // ---- multi-GPU -----------------------------------------------------------------------------------
+// The halo stream gets the HIGHEST stream priority.  Two reasons: (i) what runs on it -- pack, Send/Recv, unpack, rim
+// tiles -- is the critical path of a decomposed step and should win the arbitration against the interior tiles;
+// (ii) the runtime multiplexes the streams of one priority class onto a few hardware queues, and two streams that land
+// on the same queue run strictly one after the other (seen in a kernel trace: every launch of both streams on one
+// queue id, the rim tiles behind the interior ones): streams of different priority never share a queue.
+// PCL_HALO_PRIORITY=0 keeps the default priority (A/B).
+static hipError_t create_halo_stream(hipStream_t *st) {
+    const char *e = getenv("PCL_HALO_PRIORITY");
+    if (e && atoi(e) == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    hipError_t rc = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (rc != hipSuccess) return rc;
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+}
+
 int pcl_comm_unique_id(char uid[128]) {
     std::string err;
     if (pcl::Halo::unique_id(uid, err)) return fail(PCL_ECOMM, err);
@@ -1768,7 +1841,7 @@ int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], cons
                                        s->pitch);
     if (rc3) return fail(PCL_ECOMM, err);
     if (!s->hstream) {
-        HIP_TRY(hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking));
+        HIP_TRY(create_halo_stream(&s->hstream));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_h0, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
     }
@@ -1792,7 +1865,7 @@ int pcl_comm_init_host(pcl_solver *s, int nranks, int rank, const int neighbors[
                                             err, 1, 1, s->pitch);
     if (rc3) return fail(PCL_ECOMM, err);
     if (!s->hstream) {
-        HIP_TRY(hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking));
+        HIP_TRY(create_halo_stream(&s->hstream));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_h0, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
     }
@@ -1801,7 +1874,30 @@ int pcl_comm_init_host(pcl_solver *s, int nranks, int rank, const int neighbors[
     return PCL_OK;
 }
 
+int pcl_halo_can_overlap(pcl_solver *s, int *yes) {
+    if (!s || !yes) return fail(PCL_EINVAL, "null argument");
+    int box[4], ntiles[2];
+    *yes = s->halo.active && s->cfg.kind == PCL_KIND_CLASSIC && s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.meqn <= 8 &&
+           s->overlap == 1 && pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, 1.0), box, ntiles);
+    return PCL_OK;
+}
+
+int pcl_halo_exchange_ahead(pcl_solver *s, int on) {
+    if (!s) return fail(PCL_EINVAL, "null argument");
+    if (on) {
+        int yes = 0;
+        if (int rc = pcl_halo_can_overlap(s, &yes)) return rc;
+        if (!yes) return fail(PCL_ESTATE, "pcl_halo_exchange_ahead: needs the overlapped dimension-split 2-D step of a decomposed run "
+                                          "(pcl_comm_init done, PCL_HALO_OVERLAP=1, a block with interior x-pass tiles)");
+        if (!s->ev_y) HIP_TRY(hipEventCreateWithFlags(&s->ev_y, hipEventDisableTiming));
+    }
+    s->exchange_ahead = on ? 1 : 0;
+    s->ghosts_drop_all();
+    return PCL_OK;
+}
+
 int pcl_halo_exchange(pcl_solver *s) {
+    if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     std::string err;

@@ -162,7 +162,8 @@ def run_case(case, pyclaw):
     st = claw.solution.state
     rng = [(int(d.nstart), int(d.nend)) for d in st.grid.dimensions]
     out = {"numsteps": int(claw.solver.status["numsteps"]), "cflmax": repr(float(claw.solver.status["cflmax"])),
-           "dt": repr(float(claw.solver.dt)), "t": repr(float(claw.solution.t))}
+           "dt": repr(float(claw.solver.dt)), "t": repr(float(claw.solution.t)),
+           "exchange_ahead": bool(getattr(claw.solver, "exchange_ahead", False))}
     q = st.q
     claw.solver.teardown()
     return q, rng, out
@@ -204,8 +205,9 @@ def main():
         for o in oks:
             for m in o["msgs"]:
                 print("rank %d: %s" % (o["rank"], m))
-        print("case %s: %d ranks, blocks %s, steps %s, cflmax %s, bit-identical to the serial run: %s"
-              % (case, size, keys, out["numsteps"], out["cflmax"], all(o["ok"] for o in oks) and distinct))
+        print("case %s: %d ranks, blocks %s, steps %s, cflmax %s, exchange-ahead %s, bit-identical to the serial run: %s"
+              % (case, size, keys, out["numsteps"], out["cflmax"], out["exchange_ahead"],
+                 all(o["ok"] for o in oks) and distinct))
         ok = all(o["ok"] for o in oks) and distinct
     parallel.barrier()
     parallel.shutdown()

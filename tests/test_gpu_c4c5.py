@@ -129,14 +129,17 @@ def test_c4_blocks_decomposed_equals_serial_and_oracle_windows(case, coracle, tm
         assert np.array_equal(got, ref), (case, i0, j0, float(np.abs(got - ref).max()))
         assert not np.array_equal(ref, W.synth_euler(np.arange(i0, i0 + w) % nx, np.arange(j0, j0 + w) % ny))
     del q
-    launch(case, 4, path)
+    log = launch(case, 4, path)
+    # the dimension-split cases run with the halo sent ahead (behind the previous y pass), the unsplit one cannot
+    assert ("exchange-ahead True" in log) == (case != "c4_unsplit"), log[-600:]
 
 
 def test_c4_layout_sequential_exchange(tmp_path):
     """the C4 block shape once more with PCL_HALO_OVERLAP=0 (exchange in front of the step, one stream)"""
     q, out, path = serial_and_expect("c4_layout", tmp_path)
     del q
-    launch("c4_layout", 4, path, overlap=0)
+    log = launch("c4_layout", 4, path, overlap=0)
+    assert "exchange-ahead False" in log
 
 
 def test_c4_app_shockbubble_8192_decomposed_equals_serial(tmp_path):
@@ -149,6 +152,7 @@ def test_c4_app_shockbubble_8192_decomposed_equals_serial(tmp_path):
     del q
     log = launch("c4_app", 4, path)
     assert "steps %d" % out["numsteps"] in log
+    assert "exchange-ahead True" in log        # incl. the rejected first step: back to the pre-step buffer's ghost frame
 
 
 def sphere_window_replay(coracle, q0g, auxg, i0, j0, w, pad, dt, dx, dy):

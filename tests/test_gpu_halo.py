@@ -171,6 +171,86 @@ def test_overlapped_step_equals_periodic(mx, my, overlap, monkeypatch):
     assert not np.array_equal(res[0][0], q0)
 
 
+@pytest.mark.parametrize("mx,my", [(1000, 37), (723, 9), (4096, 2048)])
+def test_exchange_ahead_equals_periodic_with_retake(mx, my, monkeypatch):
+    """pcl_halo_exchange_ahead: the halo of the new state is exchanged behind the y pass that produced it and the next
+    step skips its own exchange.  A sequence with everything that can come between two steps -- accepted steps, a
+    rejected one (pcl_undo_step: back to the pre-step buffer and its still-filled ghost frame), a retake with a smaller
+    dt, an upload in between (the library must exchange again) -- equals the same sequence with local periodic fills,
+    bit for bit, Courant numbers included.  The ghost frame starts NaN-poisoned."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    monkeypatch.setenv("PCL_HALO_OVERLAP", "1")
+    g = 2
+    rng = np.random.default_rng(23)
+    q0 = np.empty((5, mx, my), order="F")
+    q0[0] = 1 + 0.3 * rng.random((mx, my))
+    q0[1] = 0.3 * rng.standard_normal((mx, my))
+    q0[2] = 0.2 * rng.standard_normal((mx, my))
+    q0[3] = 2.5 + 0.5 * rng.random((mx, my))
+    q0[4] = rng.random((mx, my))
+    dt = 2e-4 * 100 / mx
+    res = []
+    for with_comm in (False, True):
+        h = make_solver(L, mx, my)
+        try:
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
+                yes = C.c_int(0)
+                L.check(lib.pcl_halo_can_overlap(h, C.byref(yes)))
+                assert yes.value == 1
+                L.check(lib.pcl_halo_exchange_ahead(h, 1))
+                bc = np.full(4, -1, dtype=np.int32)
+            else:
+                bc = np.full(4, 2, dtype=np.int32)
+            poison = np.full((5, mx + 2 * g, my + 2 * g), np.nan, order="F")
+            L.check(lib.pcl_put_q(h, L.d(poison), 1))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            consts = np.zeros(4 * 8)
+            cfls = []
+
+            def step(d):
+                cfl = C.c_double()
+                L.check(lib.pcl_bc_step(h, L.i(bc), L.d(consts), d, C.cast(C.byref(cfl), L.dp)))
+                cfls.append(cfl.value)
+            step(dt)
+            step(dt)
+            step(3 * dt)                       # "rejected": undo, retake with a smaller step
+            L.check(lib.pcl_undo_step(h))
+            step(0.7 * dt)
+            step(dt)
+            mid = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(mid), 0))
+            L.check(lib.pcl_put_q(h, L.d(np.asfortranarray(mid[:, ::-1, :])), 0))    # new data: must be exchanged again
+            step(dt)
+            step(dt)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            res.append((out, cfls))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and 0 < res[0][1][0] < 1
+    assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
+
+
+def test_exchange_ahead_refused_without_overlap():
+    """no communicator / a block without interior x-pass tiles: the call says so instead of silently doing nothing"""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    h = make_solver(L, 100, 30)
+    try:
+        assert lib.pcl_halo_exchange_ahead(h, 1) != 0 and b"pcl_halo_exchange_ahead" in lib.pcl_last_error()
+        uid = C.create_string_buffer(128)
+        L.check(lib.pcl_comm_unique_id(uid))
+        L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
+        assert lib.pcl_halo_exchange_ahead(h, 1) != 0          # 100 x 30: no interior tile
+        L.check(lib.pcl_halo_exchange_ahead(h, 0))
+    finally:
+        lib.pcl_destroy(h)
+
+
 @pytest.mark.parametrize("shape", [(20, 9, 7), (70, 33, 18)])
 def test_3d_self_halo_equals_periodic(shape):
     """3-D block cut in (y, z): the exchanged plane is (j, k) with whole x-rows as elements.  One rank whose 8
