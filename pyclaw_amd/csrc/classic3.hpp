@@ -47,41 +47,17 @@ __device__ __forceinline__ void load_blk(const SweepArgs &a, const Slices3Args &
         }
 }
 
+// The pieces one slice leaves for its cells (flux3.f:168-593), in registers: qadd, fadd(i+1)-fadd(i), gadd(side, z-like
+// offset), hadd(side, y-like offset).  q / auxv: this lane's cell; blkR: its aux block (load_blk); the left lane's block
+// and state arrive by DPP shifts.  Shared by the scratch-plane kernel and the marching kernel below.
 template <class RP, int DIR>
-__global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t, int ntiles_al) {
+__device__ __forceinline__ void slice3_pieces(const double (&q)[RP::MEQN], const double (&auxv)[RP::NAUX],
+                                              const double (&blkR)[3][3][RP::NAUX], const SweepArgs &a, const Slices3Args &t,
+                                              bool cfl_ok, double &cflmax, double (&qadd)[RP::MEQN], double (&df)[RP::MEQN],
+                                              double (&gadd)[2][3][RP::MEQN], double (&hadd)[2][3][RP::MEQN]) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES, NAUX = RP::NAUX;
     using Cell = typename RP::Cell;
-    // One wavefront = one 64-cell strip along the sweep; a workgroup = 4 strips.  x direction: 4 consecutive y-like
-    // rows.  y and z directions: the lanes' accesses are `pitch` apart, so the 4 wavefronts of a workgroup -- and
-    // consecutive workgroups, kept on one XCD by xcd_logical_block -- take CONSECUTIVE i: together they use whole
-    // 128-byte lines while those are still in that XCD's L2 (with i spread over blockIdx.y every line was fetched
-    // from / written to HBM up to 16 times: 54 ms instead of 6 ms per direction at 256^3).
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    int ta, ce, cf;
-    if (DIR == 1) {
-        ta = blockIdx.x % ntiles_al;
-        ce = (blockIdx.x / ntiles_al) * 4 + wv + t.lo_e;
-        cf = blockIdx.y + t.lo_f;
-    } else {
-        const int bx = xcd_logical_block(a.xcd);
-        const int ngrp = gridDim.x / ntiles_al;                // groups of 4 consecutive i
-        const int ci = (bx % ngrp) * 4 + wv;
-        ta = bx / ngrp;
-        if (DIR == 2) { cf = ci + t.lo_f; ce = blockIdx.y + t.lo_e; }   // y sweep: z-like index = i
-        else { ce = ci + t.lo_e; cf = blockIdx.y + t.lo_f; }           // z sweep: y-like index = i
-    }
-    if (ce > t.hi_e || cf > t.hi_f) return;                    // wave-uniform
-    const int a0 = a.mbc - HALO + ta * STRIP;
-    const int ca = a0 + lane;
-    const int cc = ca < a.n_al ? ca : a.n_al - 1;
-    const long g = (long)cc * a.s_al + (long)ce * t.s_e + (long)cf * t.s_f;
-    double q[MEQN], auxv[NAUX];
-#pragma unroll
-    for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + g];
-#pragma unroll
-    for (int k = 0; k < NAUX; k++) auxv[k] = a.aux[aux_idx<RP, DIR>(k) * a.plane + g];
-    double blkR[3][3][NAUX], blkL[3][3][NAUX];
-    load_blk<RP, DIR>(a, t, g, ce, cf, blkR);     // cell l: A^+ dq of interface l sits here
+    double blkL[3][3][NAUX];
     // cell l-1 (A^- dq): the left lane's block (lane 0 has no interface of its own)
 #pragma unroll
     for (int oe = 0; oe < 3; oe++)
@@ -91,9 +67,6 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
             for (int k = 0; k < NAUX; k++) blkL[oe][of][k] = from_left(blkR[oe][of][k]);
 
     const double d = a.dtd;
-    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
-    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.m_al) && lane >= HALO && lane < WAVE - HALO;
-    double cflmax = 0.0;
 
     const Cell cR = RP::template precell<DIR>(q, a.par, auxv);
     const Cell cL = struct_from_left(cR);
@@ -144,7 +117,6 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
             cq[m] = c;
         }
     }
-    double qadd[MEQN], df[MEQN];
 #pragma unroll
     for (int m = 0; m < MEQN; m++) {
         const double amdq_r = from_right(amdq[m]), fadd_r = from_right(cq[m]);
@@ -152,7 +124,6 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
         df[m] = fadd_r - cq[m];
     }
 
-    double gadd[2][3][MEQN], hadd[2][3][MEQN];
 #pragma unroll
     for (int k = 0; k < 2; k++)
 #pragma unroll
@@ -301,6 +272,48 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
             hadd[1][0][m] = h2m; hadd[0][0][m] = h1m;
         }
     }
+}
+
+template <class RP, int DIR>
+__global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t, int ntiles_al) {
+    constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES, NAUX = RP::NAUX;
+    using Cell = typename RP::Cell;
+    // One wavefront = one 64-cell strip along the sweep; a workgroup = 4 strips.  x direction: 4 consecutive y-like
+    // rows.  y and z directions: the lanes' accesses are `pitch` apart, so the 4 wavefronts of a workgroup -- and
+    // consecutive workgroups, kept on one XCD by xcd_logical_block -- take CONSECUTIVE i: together they use whole
+    // 128-byte lines while those are still in that XCD's L2 (with i spread over blockIdx.y every line was fetched
+    // from / written to HBM up to 16 times: 54 ms instead of 6 ms per direction at 256^3).
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    int ta, ce, cf;
+    if (DIR == 1) {
+        ta = blockIdx.x % ntiles_al;
+        ce = (blockIdx.x / ntiles_al) * 4 + wv + t.lo_e;
+        cf = blockIdx.y + t.lo_f;
+    } else {
+        const int bx = xcd_logical_block(a.xcd);
+        const int ngrp = gridDim.x / ntiles_al;                // groups of 4 consecutive i
+        const int ci = (bx % ngrp) * 4 + wv;
+        ta = bx / ngrp;
+        if (DIR == 2) { cf = ci + t.lo_f; ce = blockIdx.y + t.lo_e; }   // y sweep: z-like index = i
+        else { ce = ci + t.lo_e; cf = blockIdx.y + t.lo_f; }           // z sweep: y-like index = i
+    }
+    if (ce > t.hi_e || cf > t.hi_f) return;                    // wave-uniform
+    const int a0 = a.mbc - HALO + ta * STRIP;
+    const int ca = a0 + lane;
+    const int cc = ca < a.n_al ? ca : a.n_al - 1;
+    const long g = (long)cc * a.s_al + (long)ce * t.s_e + (long)cf * t.s_f;
+    double q[MEQN], auxv[NAUX];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + g];
+#pragma unroll
+    for (int k = 0; k < NAUX; k++) auxv[k] = a.aux[aux_idx<RP, DIR>(k) * a.plane + g];
+    double blkR[3][3][NAUX];
+    load_blk<RP, DIR>(a, t, g, ce, cf, blkR);     // cell l: A^+ dq of interface l sits here
+    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
+    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.m_al) && lane >= HALO && lane < WAVE - HALO;
+    double cflmax = 0.0;
+    double qadd[MEQN], df[MEQN], gadd[2][3][MEQN], hadd[2][3][MEQN];
+    slice3_pieces<RP, DIR>(q, auxv, blkR, a, t, cfl_ok, cflmax, qadd, df, gadd, hadd);
     if (owned) {
 #pragma unroll
         for (int m = 0; m < MEQN; m++) {
@@ -317,6 +330,172 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
         }
     }
     cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
+}
+
+// ---- the marching form: no scratch planes ---------------------------------------------------------------------------
+// step3.f visits the slices of a direction in a loop nest -- x and z sweeps: z-like index outside, y-like inside; y sweep:
+// y-like outside (step3.f:176,303,470) -- and every slice adds to the 3 x 3 cells around it, so a cell receives its nine
+// contributions ordered by the OUTER index of the source slice first, the inner one second.  march3_kernel walks the
+// outer index ("march axis" M): a workgroup of NW wavefronts holds NW consecutive slices of the inner index ("wave
+// axis" W) of one 64-cell strip, and at march step m every wavefront computes the pieces of its slice (w, m) with the
+// code of the scratch-plane kernel (slice3_pieces).  A target cell (w, tm) then gets, in the reference's order,
+//     from plane m = tm-1:  slices w-1, w, w+1      (first: the accumulator starts from the cell's old value)
+//     from plane m = tm  :  slices w-1, w, w+1
+//     from plane m = tm+1:  slices w-1, w, w+1      (last: the cell is complete and is stored)
+// i.e. three accumulators per wavefront live in registers across march steps (planes m+1, m, m-1) and only the
+// contributions to the neighbouring slices w-1 / w+1 cross wavefronts, through LDS: per component 6 targets x 2
+// addends (every update is q = (q + A) + B with A the y-like and B the z-like flux term, products and signs applied by
+// the SOURCE lane -- the same operations the combine kernel did, so the bits are the same), two components per
+// exchange phase: NW * 2 * 12 * 64 doubles = 96 KB for NW = 8.  Tiles overlap by two slices along W (NW/(NW-2)
+// recompute) and the march range is cut into segments (one extra source plane at each end) so that a 256^3 grid
+// still gives every CU a workgroup.
+//     DIR 1: M = z-like (k), W = y-like (j)     DIR 2: M = y-like (k), W = z-like (i)     DIR 3: M = z-like (j), W = y-like (i)
+// For the y and z sweeps the wave axis is i: the 8 wavefronts of a workgroup touch 8 neighbouring doubles of every
+// line and workgroups that are neighbours along i run on the same XCD (xcd_logical_block), like slices3_kernel.
+struct March3Args {
+    const double *qsrc;   // what a cell's accumulator starts from: qold (x direction), the state accumulated so far (y, z)
+    double *qacc;
+    long s_w, s_m;        // strides (doubles) of the wave axis / march axis
+    int n_w, n_m, m_w, m_m;   // extents with ghost cells / interior extents
+    int seg;              // target planes per workgroup along the march axis
+    int ntiles_al, ntiles_w;
+};
+
+// the ordered pair of addends slice S gives the cell at (y-like offset oe, z-like offset of) from itself (step3.f's
+// update formulas as the combine kernel evaluates them; G_(k,j) = gadd[k-1][j+1], H_(k,j) = hadd[k-1][j+1]):
+// q := (q + A) + B.  The centre cell (0,0) has two more addends in front (qadd, -dtd*df), applied by the caller.
+template <int MEQN>
+__device__ __forceinline__ void pair3(int oe, int of, int m, double dty, double dtz, const double (&gadd)[2][3][MEQN],
+                                      const double (&hadd)[2][3][MEQN], double &A, double &B) {
+#define G_(k, j) gadd[(k)-1][(j) + 1][m]
+#define H_(k, j) hadd[(k)-1][(j) + 1][m]
+    if (oe == 0 && of == 0) { A = -(dty * (G_(2, 0) - G_(1, 0))); B = -(dtz * (H_(2, 0) - H_(1, 0))); }
+    else if (oe == -1 && of == 0) { A = -(dty * G_(1, 0)); B = -(dtz * (H_(2, -1) - H_(1, -1))); }
+    else if (oe == -1 && of == -1) { A = -(dty * G_(1, -1)); B = -(dtz * H_(1, -1)); }
+    else if (oe == 0 && of == -1) { A = -(dty * (G_(2, -1) - G_(1, -1))); B = -(dtz * H_(1, 0)); }
+    else if (oe == 1 && of == -1) { A = dty * G_(2, -1); B = -(dtz * H_(1, 1)); }
+    else if (oe == 1 && of == 0) { A = dty * G_(2, 0); B = -(dtz * (H_(2, 1) - H_(1, 1))); }
+    else if (oe == 1 && of == 1) { A = dty * G_(2, 1); B = dtz * H_(2, 1); }
+    else if (oe == 0 && of == 1) { A = -(dty * (G_(2, 1) - G_(1, 1))); B = dtz * H_(2, 0); }
+    else { A = -(dty * G_(1, 1)); B = dtz * H_(2, -1); }       // (-1, 1)
+#undef G_
+#undef H_
+}
+
+template <class RP, int DIR, int NW>
+__global__ __launch_bounds__(NW *WAVE) void march3_kernel(SweepArgs a, Slices3Args t, March3Args g) {
+    constexpr int MEQN = RP::MEQN, NAUX = RP::NAUX;
+    constexpr bool E_OUTER = DIR == 2;          // the march axis is the y-like index (y sweep), else the z-like one
+    constexpr int CP = 2;                        // components per exchange phase
+    static_assert(MEQN % CP == 0, "exchange phases take two components");
+    // xbuf[w][c][side][o][A|B][lane]: side 0 = for the slice w+1 (W offset +1), 1 = for the slice w-1; o = M offset + 1
+    __shared__ double xbuf[NW][CP][2][3][2][WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int bid = DIR == 1 ? (int)blockIdx.x : xcd_logical_block(a.xcd);
+    // W tiles fastest (neighbours along the wave axis close together), then the strips, then the march segments
+    const int tw = bid % g.ntiles_w, ta = (bid / g.ntiles_w) % g.ntiles_al, ts = bid / (g.ntiles_w * g.ntiles_al);
+    const int a0 = a.mbc - HALO + ta * STRIP;
+    const int ca = a0 + lane;
+    const int cc = ca < a.n_al ? ca : a.n_al - 1;
+    const int cw = a.mbc - 1 + tw * (NW - 2) + w;                       // this wavefront's slice along the wave axis
+    const bool w_live = cw <= a.mbc + g.m_w;                           // slices 0 .. m+1 exist (wave-uniform)
+    const int cwc = cw < g.n_w ? cw : g.n_w - 1;
+    const bool target_w = w >= 1 && w <= NW - 2 && cw >= a.mbc && cw < a.mbc + g.m_w;
+    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.m_al) && lane >= HALO && lane < WAVE - HALO && target_w;
+    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
+    const int tm0 = a.mbc + ts * g.seg;
+    const int tm1 = tm0 + g.seg < a.mbc + g.m_m ? tm0 + g.seg : a.mbc + g.m_m;      // target planes [tm0, tm1)
+    const long base = (long)cc * a.s_al + (long)cwc * g.s_w;
+    const int wl = w > 0 ? w - 1 : w, wr = w < NW - 1 ? w + 1 : w;       // (the end wavefronts are never targets)
+    double cflmax = 0.0;
+    double accP[MEQN], acc0[MEQN], accM[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) { accP[m] = 0.0; acc0[m] = 0.0; accM[m] = 0.0; }
+
+    for (int pm = tm0 - 1; pm <= tm1; pm++) {                            // source planes (all within 0 .. m+1)
+        const long gc = base + (long)pm * g.s_m;
+        double qadd[MEQN], df[MEQN], gadd[2][3][MEQN], hadd[2][3][MEQN];
+        if (w_live) {
+            double q[MEQN], auxv[NAUX], blkR[3][3][NAUX];
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + gc];
+#pragma unroll
+            for (int k = 0; k < NAUX; k++) auxv[k] = a.aux[aux_idx<RP, DIR>(k) * a.plane + gc];
+            load_blk<RP, DIR>(a, t, gc, E_OUTER ? pm : cwc, E_OUTER ? cwc : pm, blkR);
+            slice3_pieces<RP, DIR>(q, auxv, blkR, a, t, cfl_ok, cflmax, qadd, df, gadd, hadd);
+        } else {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                qadd[m] = 0.0; df[m] = 0.0;
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) { gadd[k][j][m] = 0.0; hadd[k][j][m] = 0.0; }
+            }
+        }
+        // the plane ahead starts its accumulator from the cell's value (the march never leaves the array: pm+1 <= m+3)
+        if (target_w) {      // wave-uniform
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) accP[m] = g.qsrc[m * a.plane + gc + g.s_m];
+        }
+
+#pragma unroll
+        for (int ph = 0; ph < MEQN / CP; ph++) {
+            // publish what this slice gives the slices w+1 (side 0) and w-1 (side 1) of the planes pm+1, pm, pm-1
+#pragma unroll
+            for (int c = 0; c < CP; c++) {
+                const int m = ph * CP + c;
+#pragma unroll
+                for (int side = 0; side < 2; side++)
+#pragma unroll
+                    for (int o = -1; o <= 1; o++) {
+                        const int in = side == 0 ? 1 : -1;
+                        double A, B;
+                        pair3<MEQN>(E_OUTER ? o : in, E_OUTER ? in : o, m, t.dty, t.dtz, gadd, hadd, A, B);
+                        xbuf[w][c][side][o + 1][0][lane] = A;
+                        xbuf[w][c][side][o + 1][1][lane] = B;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CP; c++) {
+                const int m = ph * CP + c;
+#pragma unroll
+                for (int o = 1; o >= -1; o--) {
+                    double v = o == 1 ? accP[m] : (o == 0 ? acc0[m] : accM[m]);
+                    v = v + xbuf[wl][c][0][o + 1][0][lane];               // from the slice w-1 (its W offset +1)
+                    v = v + xbuf[wl][c][0][o + 1][1][lane];
+                    double A, B;
+                    pair3<MEQN>(E_OUTER ? o : 0, E_OUTER ? 0 : o, m, t.dty, t.dtz, gadd, hadd, A, B);
+                    if (o == 0) { v = v + qadd[m]; v = v - a.dtd * df[m]; }
+                    v = v + A;                                             // this slice's own contribution
+                    v = v + B;
+                    v = v + xbuf[wr][c][1][o + 1][0][lane];               // from the slice w+1 (its W offset -1)
+                    v = v + xbuf[wr][c][1][o + 1][1][lane];
+                    if (o == 1) accP[m] = v; else if (o == 0) acc0[m] = v; else accM[m] = v;
+                }
+            }
+            __syncthreads();
+        }
+        // the plane behind is complete
+        if (owned && pm - 1 >= tm0 && pm - 1 < tm1) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) g.qacc[m * a.plane + gc - g.s_m] = accM[m];
+        }
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) { accM[m] = acc0[m]; acc0[m] = accP[m]; }
+    }
+    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
+}
+
+// ghost frame of the accumulated state := the old state's (the first direction writes interior cells only)
+__global__ __launch_bounds__(256) void ghost3_copy_kernel(const double *src, double *dst, int meqn, long plane, int I, int J, int K,
+                                                           long pitch, int mbc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= I) return;
+    if (i >= mbc && i < I - mbc && j >= mbc && j < J - mbc && k >= mbc && k < K - mbc) return;
+    const long c = ((long)k * J + j) * pitch + i;
+    for (int m = 0; m < meqn; m++) dst[m * plane + c] = src[m * plane + c];
 }
 
 // One thread per cell: qacc(T) += the nine slices of direction DIR around T, in the loop order of step3.f

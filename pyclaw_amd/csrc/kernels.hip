@@ -137,6 +137,41 @@ template <class RP, int DIR> int launch_unsplit3_t(const Unsplit3Launch &l, std:
     t.lo_e = a.mbc - 1; t.hi_e = a.mbc + l.m_e; t.lo_f = a.mbc - 1; t.hi_f = a.mbc + l.m_f;
     t.m3 = l.m3; t.m4 = l.m4; t.dty = l.dty; t.dtz = l.dtz;
     const int ntiles_al = (a.m_al + STRIP - 1) / STRIP;
+    static const int marching = [] { const char *e = getenv("PCL_TUNE_UNSPLIT3"); return e ? atoi(e) : 1; }();
+    if (marching) {
+        // the marching form (classic3.hpp: march3_kernel): no scratch planes, one launch per direction
+        constexpr int NW = 8;
+        March3Args g;
+        g.qsrc = DIR == 1 ? a.qin : l.qacc;
+        g.qacc = l.qacc;
+        const bool e_outer = DIR == 2;
+        g.s_w = e_outer ? l.s_f : l.s_e; g.s_m = e_outer ? l.s_e : l.s_f;
+        g.n_w = e_outer ? l.n_f : l.n_e; g.n_m = e_outer ? l.n_e : l.n_f;
+        g.m_w = e_outer ? l.m_f : l.m_e; g.m_m = e_outer ? l.m_e : l.m_f;
+        g.ntiles_al = ntiles_al;
+        g.ntiles_w = (g.m_w + (NW - 2) - 1) / (NW - 2);
+        // march segments: enough workgroups to fill the 256 CUs in whole rounds, not so many that the two extra source
+        // planes per segment cost more than the idle CUs would
+        const long per = (long)g.ntiles_al * g.ntiles_w;
+        int best = 1;
+        double best_eff = 0.0;
+        for (int ns = 1; ns <= (g.m_m + 7) / 8; ns++) {
+            const int seg = (g.m_m + ns - 1) / ns;
+            const long wgs = per * ((g.m_m + seg - 1) / seg);
+            const double eff = (double)wgs / (256.0 * ((wgs + 255) / 256)) * seg / (seg + 2.0);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = ns; }
+        }
+        g.seg = (g.m_m + best - 1) / best;
+        const int nseg = (g.m_m + g.seg - 1) / g.seg;
+        if (DIR == 1) {     // the first direction writes interior cells only: the ghost frame of the result := qold's
+            const int I = a.n_al, J = l.n_e, K = l.n_f;
+            hipLaunchKernelGGL(ghost3_copy_kernel, dim3((unsigned)((I + 255) / 256), (unsigned)J, (unsigned)K), dim3(256), 0,
+                               l.stream, a.qin, l.qacc, (int)RP::MEQN, a.plane, I, J, K, l.s_e, a.mbc);
+        }
+        hipLaunchKernelGGL((march3_kernel<RP, DIR, NW>), dim3((unsigned)(per * nseg)), dim3(NW * WAVE), 0, l.stream, a, t, g);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? PCL_OK : hip_fail(err, "march3 launch", e);
+    }
     // workgroups of 4 strips: 4 consecutive y-like rows (x direction) / 4 consecutive i (y, z directions; classic3.hpp)
     const int n4 = DIR == 2 ? l.m_f + 2 : l.m_e + 2, nother = DIR == 2 ? l.m_e + 2 : l.m_f + 2;
     hipLaunchKernelGGL((slices3_kernel<RP, DIR>), dim3((unsigned)ntiles_al * ((n4 + 3) / 4), (unsigned)nother), dim3(256), 0,

@@ -483,7 +483,10 @@ int do_unsplit3(pcl_solver *s, double dt) {
     if (m3 < 0 || m3 > 2 || m4 < 0 || m4 > 2 || (m4 > 0 && m3 == 0))
         return fail(PCL_EINVAL, "3-D order_trans must be 0, 10, 11, 20, 21 or 22 (flux3.f:46-73)");
     const size_t qbytes = ((size_t)s->total + 16) * sizeof(double);
-    for (int k = 0; k < 14; k++) {
+    // the marching kernels (classic3.hpp) keep the slices' pieces in registers and LDS; only the scratch-plane form
+    // (PCL_TUNE_UNSPLIT3=0, kept for A/B runs) needs the 14 plane sets
+    static const int marching = [] { const char *e = getenv("PCL_TUNE_UNSPLIT3"); return e ? atoi(e) : 1; }();
+    for (int k = 0; k < 14 && !marching; k++) {
         if (s->scr3[k]) continue;
         double *raw = nullptr;
         HIP_TRY(hipMalloc((void **)&raw, qbytes));
