@@ -65,6 +65,21 @@ __device__ __forceinline__ void slice3_pieces(const double (&q)[RP::MEQN], const
         for (int of = 0; of < 3; of++)
 #pragma unroll
             for (int k = 0; k < NAUX; k++) blkL[oe][of][k] = from_left(blkR[oe][of][k]);
+    // reciprocals of the impedance sums the transverse solves divide by (rp.hpp: BlkRcp); the left cell's arrive by shift
+    const typename RP::BlkRcp rcR = RP::blk_rcp(blkR);
+    typename RP::BlkRcp rcL;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            rcL.y[r][k].r = from_left(rcR.y[r][k].r);
+            rcL.z[r][k].r = from_left(rcR.z[r][k].r);
+        }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {      // the denominators themselves: one add each instead of a shift
+        rcL.y[r][0].d = blkL[0][r][0] + blkL[1][r][0]; rcL.y[r][1].d = blkL[1][r][0] + blkL[2][r][0];
+        rcL.z[r][0].d = blkL[r][0][0] + blkL[r][1][0]; rcL.z[r][1].d = blkL[r][1][0] + blkL[r][2][0];
+    }
 
     const double d = a.dtd;
 
@@ -135,20 +150,20 @@ __device__ __forceinline__ void slice3_pieces(const double (&q)[RP::MEQN], const
         // ---- transverse splits of the fluctuations (flux3.f:269-291) and of the correction waves (:299-321)
         double bmamdq[MEQN], bpamdq[MEQN], bmapdq[MEQN], bpapdq[MEQN];
         double cmamdq[MEQN], cpamdq[MEQN], cmapdq[MEQN], cpapdq[MEQN];
-        RP::template transverse3<DIR>(2, blkL, amdq, bmamdq, bpamdq);
-        RP::template transverse3<DIR>(2, blkR, apdq, bmapdq, bpapdq);
-        RP::template transverse3<DIR>(3, blkL, amdq, cmamdq, cpamdq);
-        RP::template transverse3<DIR>(3, blkR, apdq, cmapdq, cpapdq);
+        RP::template transverse3<DIR>(2, blkL, rcL, amdq, bmamdq, bpamdq);
+        RP::template transverse3<DIR>(2, blkR, rcR, apdq, bmapdq, bpapdq);
+        RP::template transverse3<DIR>(3, blkL, rcL, amdq, cmamdq, cpamdq);
+        RP::template transverse3<DIR>(3, blkR, rcR, apdq, cmapdq, cpapdq);
         double bmcqxxm[MEQN], bpcqxxm[MEQN], bmcqxxp[MEQN], bpcqxxp[MEQN];
         double cmcqxxm[MEQN], cpcqxxm[MEQN], cmcqxxp[MEQN], cpcqxxp[MEQN];
 #pragma unroll
         for (int m = 0; m < MEQN; m++)
             bmcqxxm[m] = bpcqxxm[m] = bmcqxxp[m] = bpcqxxp[m] = cmcqxxm[m] = cpcqxxm[m] = cmcqxxp[m] = cpcqxxp[m] = 0.0;
         if (t.m3 == 2) {
-            RP::template transverse3<DIR>(2, blkL, cq, bmcqxxm, bpcqxxm);
-            RP::template transverse3<DIR>(2, blkR, cq, bmcqxxp, bpcqxxp);
-            RP::template transverse3<DIR>(3, blkL, cq, cmcqxxm, cpcqxxm);
-            RP::template transverse3<DIR>(3, blkR, cq, cmcqxxp, cpcqxxp);
+            RP::template transverse3<DIR>(2, blkL, rcL, cq, bmcqxxm, bpcqxxm);
+            RP::template transverse3<DIR>(2, blkR, rcR, cq, bmcqxxp, bpcqxxp);
+            RP::template transverse3<DIR>(3, blkL, rcL, cq, cmcqxxm, cpcqxxm);
+            RP::template transverse3<DIR>(3, blkR, rcR, cq, cmcqxxp, cpcqxxp);
         }
         const double k6z = (1.0 / 6.0) * d * t.dtz, k6y = (1.0 / 6.0) * d * t.dty;
         double bmcpapdq[MEQN], bpcpapdq[MEQN], bmcpamdq[MEQN], bpcpamdq[MEQN];
@@ -171,10 +186,10 @@ __device__ __forceinline__ void slice3_pieces(const double (&q)[RP::MEQN], const
                     cpapdq2[m] = cpapdq[m]; cpamdq2[m] = cpamdq[m]; cmapdq2[m] = cmapdq[m]; cmamdq2[m] = cmamdq[m];
                 }
             }
-            RP::template transverse3t<DIR>(2, 2, blkR, cpapdq2, bmcpapdq, bpcpapdq);
-            RP::template transverse3t<DIR>(2, 2, blkL, cpamdq2, bmcpamdq, bpcpamdq);
-            RP::template transverse3t<DIR>(2, 1, blkR, cmapdq2, bmcmapdq, bpcmapdq);
-            RP::template transverse3t<DIR>(2, 1, blkL, cmamdq2, bmcmamdq, bpcmamdq);
+            RP::template transverse3t<DIR>(2, 2, blkR, rcR, cpapdq2, bmcpapdq, bpcpapdq);
+            RP::template transverse3t<DIR>(2, 2, blkL, rcL, cpamdq2, bmcpamdq, bpcpamdq);
+            RP::template transverse3t<DIR>(2, 1, blkR, rcR, cmapdq2, bmcmapdq, bpcmapdq);
+            RP::template transverse3t<DIR>(2, 1, blkL, rcL, cmamdq2, bmcmamdq, bpcmamdq);
         }
 #pragma unroll
         for (int m = 0; m < MEQN; m++) {
@@ -228,10 +243,10 @@ __device__ __forceinline__ void slice3_pieces(const double (&q)[RP::MEQN], const
             }
         }
         if (t.m4 > 0) {
-            RP::template transverse3t<DIR>(3, 2, blkR, bpapdq, bmcpapdq, bpcpapdq);
-            RP::template transverse3t<DIR>(3, 2, blkL, bpamdq, bmcpamdq, bpcpamdq);
-            RP::template transverse3t<DIR>(3, 1, blkR, bmapdq, bmcmapdq, bpcmapdq);
-            RP::template transverse3t<DIR>(3, 1, blkL, bmamdq, bmcmamdq, bpcmamdq);
+            RP::template transverse3t<DIR>(3, 2, blkR, rcR, bpapdq, bmcpapdq, bpcpapdq);
+            RP::template transverse3t<DIR>(3, 2, blkL, rcL, bpamdq, bmcpamdq, bpcpamdq);
+            RP::template transverse3t<DIR>(3, 1, blkR, rcR, bmapdq, bmcmapdq, bpcmapdq);
+            RP::template transverse3t<DIR>(3, 1, blkL, rcL, bmamdq, bmcmamdq, bpcmamdq);
         }
 #pragma unroll
         for (int m = 0; m < MEQN; m++) {
@@ -330,6 +345,199 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
         }
     }
     cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
+}
+
+// ---- the same pieces for solvers whose transverse splits are driven by ONE component ---------------------------------
+// (RP::T3_PRESSURE: acoustics.)  rpt3 / rptt3_vc_acoustics read asdq(1) and asdq(iuvw+1) (oracle/classic_oracle.c), and
+// what they are handed never has the second one: the normal fluctuations carry (p, sweep velocity), a y-like split
+// returns (p, y-like velocity), a z-like split (p, z-like velocity).  So all 16 solves per interface reduce to
+//     a1 = -t0 / (Zm + Z),  a2 = t0 / (Z + Zp)      outputs  (cm a1 Zm, -cm a1)  and  (cp a2 Zp, cp a2),
+// the G terms live in components (p, y-like velocity), the H terms in (p, z-like velocity), qadd / fadd in
+// (p, sweep velocity).  This form keeps only those: 24 doubles of gadd / hadd instead of 48, half the work after the
+// normal solve, half the exchange.  Every operation that remains is the dense code's, in its order; the ones dropped
+// have a structural zero as operand, so the values agree except, possibly, in the SIGN of a zero (v + 0.0 for
+// v = -0.0; -t0 + 0.0*Z for t0 = 0) -- the difference DESIGN section 4.1 already accepts for dmax1/dmin1.
+struct P2 { double p, v; };
+template <class RP, int DIR>
+__device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], const double (&auxv)[RP::NAUX],
+                                                const double (&blkR)[3][3][RP::NAUX], const SweepArgs &a, const Slices3Args &t,
+                                                bool cfl_ok, double &cflmax, P2 &qadd, P2 &df, P2 (&G)[2][3], P2 (&H)[2][3]) {
+    constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES, NAUX = RP::NAUX;
+    using Cell = typename RP::Cell;
+    static_assert(NAUX == 2, "aux = (impedance, sound speed)");
+    double blkL[3][3][NAUX];
+#pragma unroll
+    for (int oe = 0; oe < 3; oe++)
+#pragma unroll
+        for (int of = 0; of < 3; of++)
+#pragma unroll
+            for (int k = 0; k < NAUX; k++) blkL[oe][of][k] = from_left(blkR[oe][of][k]);
+    const double d = a.dtd;
+    const Cell cR = RP::template precell<DIR>(q, a.par, auxv);
+    const Cell cL = struct_from_left(cR);
+    double wave[MWAVES][MEQN], s[MWAVES], amdq[MEQN], apdq[MEQN];
+    RP::template solve<DIR>(cL, cR, a.par, wave, s, amdq, apdq);
+    cfl_accumulate<false, MWAVES>(s, d, d, cfl_ok, cflmax);
+    double cq[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) cq[m] = 0.0;
+    if (a.order != 1) {
+#pragma unroll
+        for (int mw = 0; mw < MWAVES; mw++) {
+            const int lim = a.mthlim[mw];
+            if (lim == 0) continue;
+            double wn = 0.0, dl = 0.0;
+            bool first = true;
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                if (!RP::template nz<DIR>(mw, m)) continue;
+                const double w = wave[mw][m], wl = from_left(w);
+                wn = first ? w * w : wn + w * w;
+                dl = first ? wl * w : dl + wl * w;
+                first = false;
+            }
+            const double dr = from_right(dl);
+            if (wn != 0.0) {
+                const double phi = philim(wn, s[mw] > 0.0 ? dl : dr, lim);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++)
+                    if (RP::template nz<DIR>(mw, m)) wave[mw][m] = phi * wave[mw][m];
+            }
+        }
+        const double dtdxave = 0.5 * (d + d);
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {
+            if (!(m == 0 || m == DIR)) continue;
+            double c = 0.0;
+            bool first = true;
+#pragma unroll
+            for (int mw = 0; mw < MWAVES; mw++)
+                if (RP::template nz<DIR>(mw, m)) {
+                    const double sa = fabs(s[mw]);
+                    const double term = 0.5 * sa * (1.0 - sa * dtdxave) * wave[mw][m];
+                    c = first ? term : c + term;
+                    first = false;
+                }
+            cq[m] = c;
+        }
+    }
+    qadd.p = -(d * apdq[0]) - d * from_right(amdq[0]);
+    qadd.v = -(d * apdq[DIR]) - d * from_right(amdq[DIR]);
+    df.p = from_right(cq[0]) - cq[0];
+    df.v = from_right(cq[DIR]) - cq[DIR];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { G[k][j].p = 0.0; G[k][j].v = 0.0; H[k][j].p = 0.0; H[k][j].v = 0.0; }
+    if (t.m3 <= 0) return;
+
+    // one split: the line (Zm, Z, Zp; cm, cp) of a block along the y-like (YL) or z-like direction at the other
+    // direction's offset r-1, driven by the pressure part t0: minus-going and plus-going result
+    auto split = [](const double (&blk)[3][3][NAUX], bool yl, int r, double t0, P2 &om, P2 &op) {
+        double zm = 0.0, zz = 0.0, zp = 0.0, cm = 0.0, cp = 0.0;
+#pragma unroll
+        for (int x = 0; x < 3; x++) {       // static indices only (r is a constant after inlining)
+            if (x == r) {
+                zm = yl ? blk[0][x][0] : blk[x][0][0]; zz = yl ? blk[1][x][0] : blk[x][1][0]; zp = yl ? blk[2][x][0] : blk[x][2][0];
+                cm = yl ? blk[0][x][1] : blk[x][0][1]; cp = yl ? blk[2][x][1] : blk[x][2][1];
+            }
+        }
+        const double a1 = Recip(zm + zz).div(-t0);
+        const double a2 = Recip(zz + zp).div(t0);
+        om.p = cm * a1 * zm; om.v = -cm * a1;
+        op.p = cp * a2 * zp; op.v = cp * a2;
+    };
+    const P2 zero{0.0, 0.0};
+    P2 bmamdq, bpamdq, bmapdq, bpapdq, cmamdq, cpamdq, cmapdq, cpapdq;
+    split(blkL, true, 1, amdq[0], bmamdq, bpamdq);
+    split(blkR, true, 1, apdq[0], bmapdq, bpapdq);
+    split(blkL, false, 1, amdq[0], cmamdq, cpamdq);
+    split(blkR, false, 1, apdq[0], cmapdq, cpapdq);
+    P2 bmcqxxm = zero, bpcqxxm = zero, bmcqxxp = zero, bpcqxxp = zero, cmcqxxm = zero, cpcqxxm = zero, cmcqxxp = zero, cpcqxxp = zero;
+    if (t.m3 == 2) {
+        split(blkL, true, 1, cq[0], bmcqxxm, bpcqxxm);
+        split(blkR, true, 1, cq[0], bmcqxxp, bpcqxxp);
+        split(blkL, false, 1, cq[0], cmcqxxm, cpcqxxm);
+        split(blkR, false, 1, cq[0], cmcqxxp, cpcqxxp);
+    }
+    const double k6z = (1.0 / 6.0) * d * t.dtz, k6y = (1.0 / 6.0) * d * t.dty;
+    P2 bmcpapdq = zero, bpcpapdq = zero, bmcpamdq = zero, bpcpamdq = zero, bmcmapdq = zero, bpcmapdq = zero, bmcmamdq = zero, bpcmamdq = zero;
+    // ---- G fluxes (y-like), flux3.f:347-452: the z-like splits (corrected by the correction waves' for m4 = 2) split
+    // again in the y-like direction, inside the z-like row they went to
+    if (t.m4 > 0) {
+        const double cpapdq2 = t.m4 == 2 ? cpapdq.p - 3.0 * cpcqxxp.p : cpapdq.p;
+        const double cpamdq2 = t.m4 == 2 ? cpamdq.p + 3.0 * cpcqxxm.p : cpamdq.p;
+        const double cmapdq2 = t.m4 == 2 ? cmapdq.p - 3.0 * cmcqxxp.p : cmapdq.p;
+        const double cmamdq2 = t.m4 == 2 ? cmamdq.p + 3.0 * cmcqxxm.p : cmamdq.p;
+        split(blkR, true, 2, cpapdq2, bmcpapdq, bpcpapdq);
+        split(blkL, true, 2, cpamdq2, bmcpamdq, bpcpamdq);
+        split(blkR, true, 0, cmapdq2, bmcmapdq, bpcmapdq);
+        split(blkL, true, 0, cmamdq2, bmcmamdq, bpcmamdq);
+    }
+    // one component of the six G (or H) values of this cell: the dense code's statements in their order.
+    // b?a?dq: first-level split in the flux's own direction; x???: second-level results; q???: correction-wave splits
+    auto six = [&](double k6, double bmap, double bpap, double bmam, double bpam, double xmcpap, double xpcpap, double xmcmap,
+                   double xpcmap, double xmcpam, double xpcpam, double xmcmam, double xpcmam, double qmp, double qpp, double qmm,
+                   double qpm, double &o10, double &o20, double &o21, double &o11, double &o2m, double &o1m) {
+        const double r_bmam = from_right(bmam), r_bpam = from_right(bpam);
+        const double r_xmcpam = from_right(xmcpam), r_xpcpam = from_right(xpcpam);
+        const double r_xmcmam = from_right(xmcmam), r_xpcmam = from_right(xpcmam);
+        const double r_qmm = from_right(qmm), r_qpm = from_right(qpm);
+        double g10 = 0.0, g20 = 0.0, g21 = 0.0, g11 = 0.0, g2m = 0.0, g1m = 0.0;
+        g10 = g10 - 0.5 * d * bmap;
+        g20 = g20 - 0.5 * d * bpap;
+        if (t.m4 > 0) {
+            g20 = g20 + k6 * (xpcpap - xpcmap);
+            g10 = g10 + k6 * (xmcpap - xmcmap);
+            g21 = g21 - k6 * xpcpap;
+            g11 = g11 - k6 * xmcpap;
+            g2m = g2m + k6 * xpcmap;
+            g1m = g1m + k6 * xmcmap;
+        }
+        if (t.m3 >= 2) {
+            g20 = g20 + d * qpp;
+            g10 = g10 + d * qmp;
+        }
+        g10 = g10 - 0.5 * d * r_bmam;
+        g20 = g20 - 0.5 * d * r_bpam;
+        if (t.m4 > 0) {
+            g20 = g20 + k6 * (r_xpcpam - r_xpcmam);
+            g10 = g10 + k6 * (r_xmcpam - r_xmcmam);
+            g21 = g21 - k6 * r_xpcpam;
+            g11 = g11 - k6 * r_xmcpam;
+            g2m = g2m + k6 * r_xpcmam;
+            g1m = g1m + k6 * r_xmcmam;
+        }
+        if (t.m3 >= 2) {
+            g20 = g20 - d * r_qpm;
+            g10 = g10 - d * r_qmm;
+        }
+        o10 = g10; o20 = g20; o21 = g21; o11 = g11; o2m = g2m; o1m = g1m;
+    };
+    six(k6z, bmapdq.p, bpapdq.p, bmamdq.p, bpamdq.p, bmcpapdq.p, bpcpapdq.p, bmcmapdq.p, bpcmapdq.p, bmcpamdq.p, bpcpamdq.p,
+        bmcmamdq.p, bpcmamdq.p, bmcqxxp.p, bpcqxxp.p, bmcqxxm.p, bpcqxxm.p,
+        G[0][1].p, G[1][1].p, G[1][2].p, G[0][2].p, G[1][0].p, G[0][0].p);
+    six(k6z, bmapdq.v, bpapdq.v, bmamdq.v, bpamdq.v, bmcpapdq.v, bpcpapdq.v, bmcmapdq.v, bpcmapdq.v, bmcpamdq.v, bpcpamdq.v,
+        bmcmamdq.v, bpcmamdq.v, bmcqxxp.v, bpcqxxp.v, bmcqxxm.v, bpcqxxm.v,
+        G[0][1].v, G[1][1].v, G[1][2].v, G[0][2].v, G[1][0].v, G[0][0].v);
+    // ---- H fluxes (z-like), flux3.f:462-590: the y-like splits (corrected for m4 = 2) split again in the z-like direction
+    P2 ymcpapdq = zero, ypcpapdq = zero, ymcpamdq = zero, ypcpamdq = zero, ymcmapdq = zero, ypcmapdq = zero, ymcmamdq = zero, ypcmamdq = zero;
+    if (t.m4 > 0) {
+        const double bpapdq2 = t.m4 == 2 ? bpapdq.p - 3.0 * bpcqxxp.p : bpapdq.p;
+        const double bpamdq2 = t.m4 == 2 ? bpamdq.p + 3.0 * bpcqxxm.p : bpamdq.p;
+        const double bmapdq2 = t.m4 == 2 ? bmapdq.p - 3.0 * bmcqxxp.p : bmapdq.p;
+        const double bmamdq2 = t.m4 == 2 ? bmamdq.p + 3.0 * bmcqxxm.p : bmamdq.p;
+        split(blkR, false, 2, bpapdq2, ymcpapdq, ypcpapdq);
+        split(blkL, false, 2, bpamdq2, ymcpamdq, ypcpamdq);
+        split(blkR, false, 0, bmapdq2, ymcmapdq, ypcmapdq);
+        split(blkL, false, 0, bmamdq2, ymcmamdq, ypcmamdq);
+    }
+    six(k6y, cmapdq.p, cpapdq.p, cmamdq.p, cpamdq.p, ymcpapdq.p, ypcpapdq.p, ymcmapdq.p, ypcmapdq.p, ymcpamdq.p, ypcpamdq.p,
+        ymcmamdq.p, ypcmamdq.p, cmcqxxp.p, cpcqxxp.p, cmcqxxm.p, cpcqxxm.p,
+        H[0][1].p, H[1][1].p, H[1][2].p, H[0][2].p, H[1][0].p, H[0][0].p);
+    six(k6y, cmapdq.v, cpapdq.v, cmamdq.v, cpamdq.v, ymcpapdq.v, ypcpapdq.v, ymcmapdq.v, ypcmapdq.v, ymcpamdq.v, ypcpamdq.v,
+        ymcmamdq.v, ypcmamdq.v, cmcqxxp.v, cpcqxxp.v, cmcqxxm.v, cpcqxxm.v,
+        H[0][1].v, H[1][1].v, H[1][2].v, H[0][2].v, H[1][0].v, H[0][0].v);
 }
 
 // ---- the marching form: no scratch planes ---------------------------------------------------------------------------
@@ -478,6 +686,163 @@ __global__ __launch_bounds__(NW *WAVE) void march3_kernel(SweepArgs a, Slices3Ar
             __syncthreads();
         }
         // the plane behind is complete
+        if (owned && pm - 1 >= tm0 && pm - 1 < tm1) {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) g.qacc[m * a.plane + gc - g.s_m] = accM[m];
+        }
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) { accM[m] = acc0[m]; acc0[m] = accP[m]; }
+    }
+    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
+}
+
+// the pair of addends of pair3 for the pressure-driven form: A from G (components p, y-like velocity), B from H
+// (components p, z-like velocity)
+__device__ __forceinline__ void pair3p(int oe, int of, double dty, double dtz, const P2 (&G)[2][3], const P2 (&H)[2][3],
+                                       P2 &A, P2 &B) {
+#define G_(k, j, c) G[(k)-1][(j) + 1].c
+#define H_(k, j, c) H[(k)-1][(j) + 1].c
+#define PAIR_(EA, EB) { A.p = EA(p); A.v = EA(v); B.p = EB(p); B.v = EB(v); }
+#define A00(c) -(dty * (G_(2, 0, c) - G_(1, 0, c)))
+#define B00(c) -(dtz * (H_(2, 0, c) - H_(1, 0, c)))
+#define AM0(c) -(dty * G_(1, 0, c))
+#define BM0(c) -(dtz * (H_(2, -1, c) - H_(1, -1, c)))
+#define AMM(c) -(dty * G_(1, -1, c))
+#define BMM(c) -(dtz * H_(1, -1, c))
+#define A0M(c) -(dty * (G_(2, -1, c) - G_(1, -1, c)))
+#define B0M(c) -(dtz * H_(1, 0, c))
+#define APM(c) (dty * G_(2, -1, c))
+#define BPM(c) -(dtz * H_(1, 1, c))
+#define AP0(c) (dty * G_(2, 0, c))
+#define BP0(c) -(dtz * (H_(2, 1, c) - H_(1, 1, c)))
+#define APP(c) (dty * G_(2, 1, c))
+#define BPP(c) (dtz * H_(2, 1, c))
+#define A0P(c) -(dty * (G_(2, 1, c) - G_(1, 1, c)))
+#define B0P(c) (dtz * H_(2, 0, c))
+#define AMP(c) -(dty * G_(1, 1, c))
+#define BMP(c) (dtz * H_(2, -1, c))
+    if (oe == 0 && of == 0) PAIR_(A00, B00)
+    else if (oe == -1 && of == 0) PAIR_(AM0, BM0)
+    else if (oe == -1 && of == -1) PAIR_(AMM, BMM)
+    else if (oe == 0 && of == -1) PAIR_(A0M, B0M)
+    else if (oe == 1 && of == -1) PAIR_(APM, BPM)
+    else if (oe == 1 && of == 0) PAIR_(AP0, BP0)
+    else if (oe == 1 && of == 1) PAIR_(APP, BPP)
+    else if (oe == 0 && of == 1) PAIR_(A0P, B0P)
+    else PAIR_(AMP, BMP)
+#undef G_
+#undef H_
+#undef PAIR_
+#undef A00
+#undef B00
+#undef AM0
+#undef BM0
+#undef AMM
+#undef BMM
+#undef A0M
+#undef B0M
+#undef APM
+#undef BPM
+#undef AP0
+#undef BP0
+#undef APP
+#undef BPP
+#undef A0P
+#undef B0P
+#undef AMP
+#undef BMP
+}
+
+// march3_kernel for the pressure-driven form (slice3_pieces_p): component 0 receives both addends of every contribution,
+// the y-like velocity only A, the z-like velocity only B, the sweep velocity only the slice's own qadd / fadd -- 24
+// doubles per lane cross wavefronts instead of 48, in ONE exchange phase (two barriers per march step).
+template <class RP, int DIR, int NW>
+__global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3Args t, March3Args g) {
+    constexpr int MEQN = RP::MEQN, NAUX = RP::NAUX;
+    static_assert(MEQN == 4 && RP::T3_PRESSURE, "q = (p, u, v, w)");
+    constexpr bool E_OUTER = DIR == 2;
+    constexpr int IE = DIR % 3 + 1, IF = (DIR + 1) % 3 + 1;      // components of the y-like / z-like velocity
+    // xbuf[w][side][o][A.p | B.p | A.v | B.v][lane]: side 0 = for the slice w+1, 1 = for the slice w-1; o = M offset + 1
+    __shared__ double xbuf[NW][2][3][4][WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int bid = DIR == 1 ? (int)blockIdx.x : xcd_logical_block(a.xcd);
+    const int tw = bid % g.ntiles_w, ta = (bid / g.ntiles_w) % g.ntiles_al, ts = bid / (g.ntiles_w * g.ntiles_al);
+    const int a0 = a.mbc - HALO + ta * STRIP;
+    const int ca = a0 + lane;
+    const int cc = ca < a.n_al ? ca : a.n_al - 1;
+    const int cw = a.mbc - 1 + tw * (NW - 2) + w;
+    const bool w_live = cw <= a.mbc + g.m_w;                           // wave-uniform
+    const int cwc = cw < g.n_w ? cw : g.n_w - 1;
+    const bool target_w = w >= 1 && w <= NW - 2 && cw >= a.mbc && cw < a.mbc + g.m_w;
+    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.m_al) && lane >= HALO && lane < WAVE - HALO && target_w;
+    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
+    const int tm0 = a.mbc + ts * g.seg;
+    const int tm1 = tm0 + g.seg < a.mbc + g.m_m ? tm0 + g.seg : a.mbc + g.m_m;
+    const long base = (long)cc * a.s_al + (long)cwc * g.s_w;
+    const int wl = w > 0 ? w - 1 : w, wr = w < NW - 1 ? w + 1 : w;
+    double cflmax = 0.0;
+    double accP[MEQN], acc0[MEQN], accM[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) { accP[m] = 0.0; acc0[m] = 0.0; accM[m] = 0.0; }
+
+    for (int pm = tm0 - 1; pm <= tm1; pm++) {
+        const long gc = base + (long)pm * g.s_m;
+        P2 qadd{0.0, 0.0}, df{0.0, 0.0}, G[2][3], H[2][3];
+        if (w_live) {
+            double q[MEQN], auxv[NAUX], blkR[3][3][NAUX];
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + gc];
+#pragma unroll
+            for (int k = 0; k < NAUX; k++) auxv[k] = a.aux[aux_idx<RP, DIR>(k) * a.plane + gc];
+            load_blk<RP, DIR>(a, t, gc, E_OUTER ? pm : cwc, E_OUTER ? cwc : pm, blkR);
+            slice3_pieces_p<RP, DIR>(q, auxv, blkR, a, t, cfl_ok, cflmax, qadd, df, G, H);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) { G[k][j].p = 0.0; G[k][j].v = 0.0; H[k][j].p = 0.0; H[k][j].v = 0.0; }
+        }
+        if (target_w) {      // wave-uniform
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) accP[m] = g.qsrc[m * a.plane + gc + g.s_m];
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++)
+#pragma unroll
+            for (int o = -1; o <= 1; o++) {
+                const int in = side == 0 ? 1 : -1;
+                P2 A, B;
+                pair3p(E_OUTER ? o : in, E_OUTER ? in : o, t.dty, t.dtz, G, H, A, B);
+                xbuf[w][side][o + 1][0][lane] = A.p;
+                xbuf[w][side][o + 1][1][lane] = B.p;
+                xbuf[w][side][o + 1][2][lane] = A.v;
+                xbuf[w][side][o + 1][3][lane] = B.v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int o = 1; o >= -1; o--) {
+            double *acc = o == 1 ? accP : (o == 0 ? acc0 : accM);
+            P2 A, B;
+            pair3p(E_OUTER ? o : 0, E_OUTER ? 0 : o, t.dty, t.dtz, G, H, A, B);
+            double vp = acc[0], ve = acc[IE], vf = acc[IF];
+            vp = vp + xbuf[wl][0][o + 1][0][lane];                      // from the slice w-1
+            vp = vp + xbuf[wl][0][o + 1][1][lane];
+            ve = ve + xbuf[wl][0][o + 1][2][lane];
+            vf = vf + xbuf[wl][0][o + 1][3][lane];
+            if (o == 0) {
+                vp = vp + qadd.p; vp = vp - a.dtd * df.p;
+                acc[DIR] = (acc[DIR] + qadd.v) - a.dtd * df.v;
+            }
+            vp = vp + A.p; vp = vp + B.p;                               // this slice's own
+            ve = ve + A.v;
+            vf = vf + B.v;
+            vp = vp + xbuf[wr][1][o + 1][0][lane];                      // from the slice w+1
+            vp = vp + xbuf[wr][1][o + 1][1][lane];
+            ve = ve + xbuf[wr][1][o + 1][2][lane];
+            vf = vf + xbuf[wr][1][o + 1][3][lane];
+            acc[0] = vp; acc[IE] = ve; acc[IF] = vf;
+        }
+        __syncthreads();
         if (owned && pm - 1 >= tm0 && pm - 1 < tm1) {
 #pragma unroll
             for (int m = 0; m < MEQN; m++) g.qacc[m * a.plane + gc - g.s_m] = accM[m];

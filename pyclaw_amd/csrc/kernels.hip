@@ -168,7 +168,11 @@ template <class RP, int DIR> int launch_unsplit3_t(const Unsplit3Launch &l, std:
             hipLaunchKernelGGL(ghost3_copy_kernel, dim3((unsigned)((I + 255) / 256), (unsigned)J, (unsigned)K), dim3(256), 0,
                                l.stream, a.qin, l.qacc, (int)RP::MEQN, a.plane, I, J, K, l.s_e, a.mbc);
         }
-        hipLaunchKernelGGL((march3_kernel<RP, DIR, NW>), dim3((unsigned)(per * nseg)), dim3(NW * WAVE), 0, l.stream, a, t, g);
+        static const int dense = [] { const char *e = getenv("PCL_TUNE_UNSPLIT3_DENSE"); return e ? atoi(e) : 0; }();
+        if (RP::T3_PRESSURE && !dense)
+            hipLaunchKernelGGL((march3p_kernel<RP, DIR, NW>), dim3((unsigned)(per * nseg)), dim3(NW * WAVE), 0, l.stream, a, t, g);
+        else
+            hipLaunchKernelGGL((march3_kernel<RP, DIR, NW>), dim3((unsigned)(per * nseg)), dim3(NW * WAVE), 0, l.stream, a, t, g);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? PCL_OK : hip_fail(err, "march3 launch", e);
     }

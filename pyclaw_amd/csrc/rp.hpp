@@ -617,6 +617,8 @@ struct VcAcoustics2D {
 // q = (p, u, v, w); aux(1) = Z, aux(2) = c.  DIR = 1,2,3 selects the normal velocity q(DIR).
 struct VcAcoustics3D {
     static constexpr int MEQN = 4, MWAVES = 2, NAUX = 2, NAUX_T = 2;
+    // the transverse solvers are driven by the pressure component alone (classic3.hpp: slice3_pieces_p)
+    static constexpr bool T3_PRESSURE = true;
     template <int IXY> __host__ __device__ static constexpr int aux_index(int k) { return k; }
     template <int IXY> __host__ __device__ static constexpr int auxt_index(int k) { return k; }
     struct Cell { double q[4]; double z, c; };
@@ -658,21 +660,39 @@ struct VcAcoustics3D {
     __device__ static __forceinline__ double pick(const double (&a)[4], int iuvw) {
         return iuvw == 1 ? a[1] : (iuvw == 2 ? a[2] : a[3]);
     }
+    // The 16 transverse solves of one interface divide by sums of neighbouring impedances, and only twelve different
+    // sums occur in a cell's 3 x 3 block: the pairs (lower, centre) and (centre, upper) of its three lines along the
+    // y-like and its three lines along the z-like direction.  BlkRcp holds their reciprocals (refined once; every
+    // quotient is then the correctly rounded Markstein form of Recip::div, like the normal solve's) -- 12 reciprocals
+    // per lane instead of 32 IEEE divisions, and the left neighbour's set arrives by DPP shift.
+    struct BlkRcp {
+        Recip y[3][2];     // y[r][0|1]: line along the y-like direction at z-like offset r-1: Z(-1)+Z(0), Z(0)+Z(+1)
+        Recip z[3][2];     // z[r][0|1]: line along the z-like direction at y-like offset r-1
+    };
+    __device__ static __forceinline__ BlkRcp blk_rcp(const double (&blk)[3][3][2]) {
+        BlkRcp b;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            b.y[r][0] = Recip(blk[0][r][0] + blk[1][r][0]); b.y[r][1] = Recip(blk[1][r][0] + blk[2][r][0]);
+            b.z[r][0] = Recip(blk[r][0][0] + blk[r][1][0]); b.z[r][1] = Recip(blk[r][1][0] + blk[r][2][0]);
+        }
+        return b;
+    }
     template <int DIR>
-    __device__ static __forceinline__ void transverse3(int icoor, const double (&blk)[3][3][2], const double (&asdq)[4],
-                                                       double (&bm)[4], double (&bp)[4]) {
+    __device__ static __forceinline__ void transverse3(int icoor, const double (&blk)[3][3][2], const BlkRcp &rc,
+                                                       const double (&asdq)[4], double (&bm)[4], double (&bp)[4]) {
         int iuvw = DIR + icoor - 1;
         if (iuvw > 3) iuvw -= 3;
         double t[4] = {asdq[0], pick(asdq, iuvw), 0.0, 0.0};
         double om[4], op[4];
         if (icoor == 2)
-            split3x(blk[0][1][0], blk[1][1][0], blk[2][1][0], blk[0][1][1], blk[2][1][1], t, om, op);
+            split3x(blk[0][1][0], blk[1][1][0], blk[2][1][0], blk[0][1][1], blk[2][1][1], rc.y[1][0], rc.y[1][1], t, om, op);
         else
-            split3x(blk[1][0][0], blk[1][1][0], blk[1][2][0], blk[1][0][1], blk[1][2][1], t, om, op);
+            split3x(blk[1][0][0], blk[1][1][0], blk[1][2][0], blk[1][0][1], blk[1][2][1], rc.z[1][0], rc.z[1][1], t, om, op);
         place(iuvw, om, op, bm, bp);
     }
     template <int DIR>
-    __device__ static __forceinline__ void transverse3t(int icoor, int impt, const double (&blk)[3][3][2],
+    __device__ static __forceinline__ void transverse3t(int icoor, int impt, const double (&blk)[3][3][2], const BlkRcp &rc,
                                                         const double (&bsasdq)[4], double (&cmo)[4], double (&cpo)[4]) {
         int iuvw = DIR + icoor - 1;
         if (iuvw > 3) iuvw -= 3;
@@ -680,9 +700,11 @@ struct VcAcoustics3D {
         double om[4], op[4];
         const int r = impt == 1 ? 0 : 2;
         if (icoor == 2)       // new split in the y-like direction, inside the z-like row the first split went to
-            split3x(sel(blk, 0, r, 0), sel(blk, 1, r, 0), sel(blk, 2, r, 0), sel(blk, 0, r, 1), sel(blk, 2, r, 1), t, om, op);
+            split3x(sel(blk, 0, r, 0), sel(blk, 1, r, 0), sel(blk, 2, r, 0), sel(blk, 0, r, 1), sel(blk, 2, r, 1),
+                    r == 0 ? rc.y[0][0] : rc.y[2][0], r == 0 ? rc.y[0][1] : rc.y[2][1], t, om, op);
         else                  // new split in the z-like direction, inside the y-like row the first split went to
-            split3x(sel(blk, r, 0, 0), sel(blk, r, 1, 0), sel(blk, r, 2, 0), sel(blk, r, 0, 1), sel(blk, r, 2, 1), t, om, op);
+            split3x(sel(blk, r, 0, 0), sel(blk, r, 1, 0), sel(blk, r, 2, 0), sel(blk, r, 0, 1), sel(blk, r, 2, 1),
+                    r == 0 ? rc.z[0][0] : rc.z[2][0], r == 0 ? rc.z[0][1] : rc.z[2][1], t, om, op);
         place(iuvw, om, op, cmo, cpo);
     }
     // blk[a][b][k] with a or b in {0, 2} chosen at run time, written with static indices
@@ -699,9 +721,10 @@ struct VcAcoustics3D {
     }
     // t = (asdq(1), asdq(iuvw+1)); om/op = (pressure part, velocity part)
     __device__ static __forceinline__ void split3x(double zm, double zz, double zp, double cm, double cp,
+                                                   const Recip &by_m, const Recip &by_p,        // 1/(zm+zz), 1/(zz+zp)
                                                    const double (&t)[4], double (&om)[4], double (&op)[4]) {
-        const double a1 = fdiv_ieee(-t[0] + t[1] * zz, zm + zz);
-        const double a2 = fdiv_ieee(t[0] + t[1] * zz, zz + zp);
+        const double a1 = by_m.div(-t[0] + t[1] * zz);
+        const double a2 = by_p.div(t[0] + t[1] * zz);
         om[0] = cm * a1 * zm; om[1] = -cm * a1; om[2] = om[3] = 0.0;
         op[0] = cp * a2 * zp; op[1] = cp * a2; op[2] = op[3] = 0.0;
     }
