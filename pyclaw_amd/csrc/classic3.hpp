@@ -357,6 +357,9 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
 // normal solve, half the exchange.  Every operation that remains is the dense code's, in its order; the ones dropped
 // have a structural zero as operand, so the values agree except, possibly, in the SIGN of a zero (v + 0.0 for
 // v = -0.0; -t0 + 0.0*Z for t0 = 0) -- the difference DESIGN section 4.1 already accepts for dmax1/dmin1.
+#ifndef PCL_T3_SHARED_RCP
+#define PCL_T3_SHARED_RCP 0      /* 1: spills at the 256-VGPR budget of 8 wavefronts (140 B of scratch per lane) */
+#endif
 struct P2 { double p, v; };
 template <class RP, int DIR>
 __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], const double (&auxv)[RP::NAUX],
@@ -433,7 +436,25 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
 
     // one split: the line (Zm, Z, Zp; cm, cp) of a block along the y-like (YL) or z-like direction at the other
     // direction's offset r-1, driven by the pressure part t0: minus-going and plus-going result
-    auto split = [](const double (&blk)[3][3][NAUX], bool yl, int r, double t0, P2 &om, P2 &op) {
+    // reciprocals of the twelve impedance sums of the block (RP::BlkRcp); the left cell's set is the left lane's
+#if PCL_T3_SHARED_RCP
+    const typename RP::BlkRcp rcR = RP::blk_rcp(blkR);
+    typename RP::BlkRcp rcL;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            rcL.y[r][k].r = from_left(rcR.y[r][k].r);
+            rcL.z[r][k].r = from_left(rcR.z[r][k].r);
+        }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        rcL.y[r][0].d = blkL[0][r][0] + blkL[1][r][0]; rcL.y[r][1].d = blkL[1][r][0] + blkL[2][r][0];
+        rcL.z[r][0].d = blkL[r][0][0] + blkL[r][1][0]; rcL.z[r][1].d = blkL[r][1][0] + blkL[r][2][0];
+    }
+#endif
+    auto split = [&](bool left, bool yl, int r, double t0, P2 &om, P2 &op) {
+        const double (&blk)[3][3][NAUX] = left ? blkL : blkR;
         double zm = 0.0, zz = 0.0, zp = 0.0, cm = 0.0, cp = 0.0;
 #pragma unroll
         for (int x = 0; x < 3; x++) {       // static indices only (r is a constant after inlining)
@@ -442,23 +463,33 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
                 cm = yl ? blk[0][x][1] : blk[x][0][1]; cp = yl ? blk[2][x][1] : blk[x][2][1];
             }
         }
+#if PCL_T3_SHARED_RCP
+        const typename RP::BlkRcp &rc = left ? rcL : rcR;
+        Recip by_m, by_p;
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+            if (x == r) { by_m = yl ? rc.y[x][0] : rc.z[x][0]; by_p = yl ? rc.y[x][1] : rc.z[x][1]; }
+        const double a1 = by_m.div(-t0);
+        const double a2 = by_p.div(t0);
+#else
         const double a1 = Recip(zm + zz).div(-t0);
         const double a2 = Recip(zz + zp).div(t0);
+#endif
         om.p = cm * a1 * zm; om.v = -cm * a1;
         op.p = cp * a2 * zp; op.v = cp * a2;
     };
     const P2 zero{0.0, 0.0};
     P2 bmamdq, bpamdq, bmapdq, bpapdq, cmamdq, cpamdq, cmapdq, cpapdq;
-    split(blkL, true, 1, amdq[0], bmamdq, bpamdq);
-    split(blkR, true, 1, apdq[0], bmapdq, bpapdq);
-    split(blkL, false, 1, amdq[0], cmamdq, cpamdq);
-    split(blkR, false, 1, apdq[0], cmapdq, cpapdq);
+    split(true, true, 1, amdq[0], bmamdq, bpamdq);
+    split(false, true, 1, apdq[0], bmapdq, bpapdq);
+    split(true, false, 1, amdq[0], cmamdq, cpamdq);
+    split(false, false, 1, apdq[0], cmapdq, cpapdq);
     P2 bmcqxxm = zero, bpcqxxm = zero, bmcqxxp = zero, bpcqxxp = zero, cmcqxxm = zero, cpcqxxm = zero, cmcqxxp = zero, cpcqxxp = zero;
     if (t.m3 == 2) {
-        split(blkL, true, 1, cq[0], bmcqxxm, bpcqxxm);
-        split(blkR, true, 1, cq[0], bmcqxxp, bpcqxxp);
-        split(blkL, false, 1, cq[0], cmcqxxm, cpcqxxm);
-        split(blkR, false, 1, cq[0], cmcqxxp, cpcqxxp);
+        split(true, true, 1, cq[0], bmcqxxm, bpcqxxm);
+        split(false, true, 1, cq[0], bmcqxxp, bpcqxxp);
+        split(true, false, 1, cq[0], cmcqxxm, cpcqxxm);
+        split(false, false, 1, cq[0], cmcqxxp, cpcqxxp);
     }
     const double k6z = (1.0 / 6.0) * d * t.dtz, k6y = (1.0 / 6.0) * d * t.dty;
     P2 bmcpapdq = zero, bpcpapdq = zero, bmcpamdq = zero, bpcpamdq = zero, bmcmapdq = zero, bpcmapdq = zero, bmcmamdq = zero, bpcmamdq = zero;
@@ -469,10 +500,10 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
         const double cpamdq2 = t.m4 == 2 ? cpamdq.p + 3.0 * cpcqxxm.p : cpamdq.p;
         const double cmapdq2 = t.m4 == 2 ? cmapdq.p - 3.0 * cmcqxxp.p : cmapdq.p;
         const double cmamdq2 = t.m4 == 2 ? cmamdq.p + 3.0 * cmcqxxm.p : cmamdq.p;
-        split(blkR, true, 2, cpapdq2, bmcpapdq, bpcpapdq);
-        split(blkL, true, 2, cpamdq2, bmcpamdq, bpcpamdq);
-        split(blkR, true, 0, cmapdq2, bmcmapdq, bpcmapdq);
-        split(blkL, true, 0, cmamdq2, bmcmamdq, bpcmamdq);
+        split(false, true, 2, cpapdq2, bmcpapdq, bpcpapdq);
+        split(true, true, 2, cpamdq2, bmcpamdq, bpcpamdq);
+        split(false, true, 0, cmapdq2, bmcmapdq, bpcmapdq);
+        split(true, true, 0, cmamdq2, bmcmamdq, bpcmamdq);
     }
     // one component of the six G (or H) values of this cell: the dense code's statements in their order.
     // b?a?dq: first-level split in the flux's own direction; x???: second-level results; q???: correction-wave splits
@@ -527,10 +558,10 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
         const double bpamdq2 = t.m4 == 2 ? bpamdq.p + 3.0 * bpcqxxm.p : bpamdq.p;
         const double bmapdq2 = t.m4 == 2 ? bmapdq.p - 3.0 * bmcqxxp.p : bmapdq.p;
         const double bmamdq2 = t.m4 == 2 ? bmamdq.p + 3.0 * bmcqxxm.p : bmamdq.p;
-        split(blkR, false, 2, bpapdq2, ymcpapdq, ypcpapdq);
-        split(blkL, false, 2, bpamdq2, ymcpamdq, ypcpamdq);
-        split(blkR, false, 0, bmapdq2, ymcmapdq, ypcmapdq);
-        split(blkL, false, 0, bmamdq2, ymcmamdq, ypcmamdq);
+        split(false, false, 2, bpapdq2, ymcpapdq, ypcpapdq);
+        split(true, false, 2, bpamdq2, ymcpamdq, ypcpamdq);
+        split(false, false, 0, bmapdq2, ymcmapdq, ypcmapdq);
+        split(true, false, 0, bmamdq2, ymcmamdq, ypcmamdq);
     }
     six(k6y, cmapdq.p, cpapdq.p, cmamdq.p, cpamdq.p, ymcpapdq.p, ypcpapdq.p, ymcmapdq.p, ypcmapdq.p, ymcpamdq.p, ypcpamdq.p,
         ymcmamdq.p, ypcmamdq.p, cmcqxxp.p, cpcqxxp.p, cmcqxxm.p, cpcqxxm.p,
@@ -785,26 +816,55 @@ __global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3A
 #pragma unroll
     for (int m = 0; m < MEQN; m++) { accP[m] = 0.0; acc0[m] = 0.0; accM[m] = 0.0; }
 
+    // The 3 x 3 aux block and the cell itself travel with the march: per step only the face ahead (three cells of the
+    // wave axis at plane pm+2) and the next cell are loaded -- 6 + 4 loads instead of 18 + 2 + 4, issued BEFORE the
+    // exchange so that they are in flight through it.  (For the y and z sweeps the lanes of a load are `pitch` apart:
+    // 64 lines per instruction; with 28 such loads per step the texture addresser, not the VALU, set the pace.)
+    double blkR[3][3][NAUX], qc[MEQN];
+    {
+        const long g0 = base + (long)(tm0 - 1) * g.s_m;
+        load_blk<RP, DIR>(a, t, g0, E_OUTER ? tm0 - 1 : cwc, E_OUTER ? cwc : tm0 - 1, blkR);
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) qc[m] = a.qin[m * a.plane + g0];
+    }
+    const long sw_lo = cwc > 0 ? -g.s_w : 0, sw_hi = cwc + 1 < g.n_w ? g.s_w : 0;      // wave-axis neighbours, clamped like load_blk
     for (int pm = tm0 - 1; pm <= tm1; pm++) {
         const long gc = base + (long)pm * g.s_m;
         P2 qadd{0.0, 0.0}, df{0.0, 0.0}, G[2][3], H[2][3];
         if (w_live) {
-            double q[MEQN], auxv[NAUX], blkR[3][3][NAUX];
+            double auxv[NAUX];
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + gc];
-#pragma unroll
-            for (int k = 0; k < NAUX; k++) auxv[k] = a.aux[aux_idx<RP, DIR>(k) * a.plane + gc];
-            load_blk<RP, DIR>(a, t, gc, E_OUTER ? pm : cwc, E_OUTER ? cwc : pm, blkR);
-            slice3_pieces_p<RP, DIR>(q, auxv, blkR, a, t, cfl_ok, cflmax, qadd, df, G, H);
+            for (int k = 0; k < NAUX; k++) auxv[k] = blkR[1][1][k];
+            slice3_pieces_p<RP, DIR>(qc, auxv, blkR, a, t, cfl_ok, cflmax, qadd, df, G, H);
         } else {
 #pragma unroll
             for (int k = 0; k < 2; k++)
 #pragma unroll
                 for (int j = 0; j < 3; j++) { G[k][j].p = 0.0; G[k][j].v = 0.0; H[k][j].p = 0.0; H[k][j].v = 0.0; }
         }
-        if (target_w) {      // wave-uniform
+        // the next plane: its cell (x direction: also what the accumulator of that plane starts from) and the aux face
+        // two planes ahead
+        double qn[MEQN], face[3][NAUX];
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) accP[m] = g.qsrc[m * a.plane + gc + g.s_m];
+        for (int m = 0; m < MEQN; m++) qn[m] = a.qin[m * a.plane + gc + g.s_m];
+        if (pm < tm1) {      // uniform
+#pragma unroll
+            for (int k = 0; k < NAUX; k++) {
+                const long at = aux_idx<RP, DIR>(k) * a.plane + gc + 2 * g.s_m;
+                face[0][k] = a.aux[at + sw_lo]; face[1][k] = a.aux[at]; face[2][k] = a.aux[at + sw_hi];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NAUX; k++) { face[0][k] = blkR[1][1][k]; face[1][k] = blkR[1][1][k]; face[2][k] = blkR[1][1][k]; }
+        }
+        if (target_w) {      // wave-uniform
+            if (DIR == 1) {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) accP[m] = qn[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) accP[m] = g.qsrc[m * a.plane + gc + g.s_m];
+            }
         }
 #pragma unroll
         for (int side = 0; side < 2; side++)
@@ -848,7 +908,15 @@ __global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3A
             for (int m = 0; m < MEQN; m++) g.qacc[m * a.plane + gc - g.s_m] = accM[m];
         }
 #pragma unroll
-        for (int m = 0; m < MEQN; m++) { accM[m] = acc0[m]; acc0[m] = accP[m]; }
+        for (int m = 0; m < MEQN; m++) { accM[m] = acc0[m]; acc0[m] = accP[m]; qc[m] = qn[m]; }
+        // the block moves one plane along the march axis (y sweep: the y-like index, else the z-like one)
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int k = 0; k < NAUX; k++) {
+                if (E_OUTER) { blkR[0][x][k] = blkR[1][x][k]; blkR[1][x][k] = blkR[2][x][k]; blkR[2][x][k] = face[x][k]; }
+                else { blkR[x][0][k] = blkR[x][1][k]; blkR[x][1][k] = blkR[x][2][k]; blkR[x][2][k] = face[x][k]; }
+            }
     }
     cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
 }
