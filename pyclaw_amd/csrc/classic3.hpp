@@ -368,13 +368,6 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES, NAUX = RP::NAUX;
     using Cell = typename RP::Cell;
     static_assert(NAUX == 2, "aux = (impedance, sound speed)");
-    double blkL[3][3][NAUX];
-#pragma unroll
-    for (int oe = 0; oe < 3; oe++)
-#pragma unroll
-        for (int of = 0; of < 3; of++)
-#pragma unroll
-            for (int k = 0; k < NAUX; k++) blkL[oe][of][k] = from_left(blkR[oe][of][k]);
     const double d = a.dtd;
     const Cell cR = RP::template precell<DIR>(q, a.par, auxv);
     const Cell cL = struct_from_left(cR);
@@ -434,86 +427,57 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
         for (int j = 0; j < 3; j++) { G[k][j].p = 0.0; G[k][j].v = 0.0; H[k][j].p = 0.0; H[k][j].v = 0.0; }
     if (t.m3 <= 0) return;
 
-    // one split: the line (Zm, Z, Zp; cm, cp) of a block along the y-like (YL) or z-like direction at the other
-    // direction's offset r-1, driven by the pressure part t0: minus-going and plus-going result
-    // reciprocals of the twelve impedance sums of the block (RP::BlkRcp); the left cell's set is the left lane's
-#if PCL_T3_SHARED_RCP
-    const typename RP::BlkRcp rcR = RP::blk_rcp(blkR);
-    typename RP::BlkRcp rcL;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            rcL.y[r][k].r = from_left(rcR.y[r][k].r);
-            rcL.z[r][k].r = from_left(rcR.z[r][k].r);
-        }
+    // Every split below uses THIS cell's block: A^+ dq and the correction flux of interface l belong to cell l, and
+    // A^- dq / the correction flux of interface l+1 -- which the dense code splits in lane l+1 with the left
+    // neighbour's block and then shifts back -- are fetched from the right-hand lane first and split here.  Same
+    // operands, same operations, one lane to the left: the left neighbour's block, its reciprocals and 32 shifts of
+    // results disappear, and the twelve impedance sums of the block are inverted once.
+    const double aP = apdq[0], aM = from_right(amdq[0]);
+    const double kP = cq[0], kM = from_right(cq[0]);
+    Recip ry[3][2], rz[3][2];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        rcL.y[r][0].d = blkL[0][r][0] + blkL[1][r][0]; rcL.y[r][1].d = blkL[1][r][0] + blkL[2][r][0];
-        rcL.z[r][0].d = blkL[r][0][0] + blkL[r][1][0]; rcL.z[r][1].d = blkL[r][1][0] + blkL[r][2][0];
+        ry[r][0] = Recip(blkR[0][r][0] + blkR[1][r][0]); ry[r][1] = Recip(blkR[1][r][0] + blkR[2][r][0]);
+        rz[r][0] = Recip(blkR[r][0][0] + blkR[r][1][0]); rz[r][1] = Recip(blkR[r][1][0] + blkR[r][2][0]);
     }
-#endif
-    auto split = [&](bool left, bool yl, int r, double t0, P2 &om, P2 &op) {
-        const double (&blk)[3][3][NAUX] = left ? blkL : blkR;
-        double zm = 0.0, zz = 0.0, zp = 0.0, cm = 0.0, cp = 0.0;
+    // one split: the line (Zm, Z, Zp; cm, cp) of the block along the y-like (yl) or z-like direction at the other
+    // direction's offset r-1, driven by the pressure part t0: minus-going and plus-going result
+    auto split = [&](bool yl, int r, double t0, P2 &om, P2 &op) {
+        double zm = 0.0, zp = 0.0, cm = 0.0, cp = 0.0;
+        Recip by_m, by_p;
 #pragma unroll
         for (int x = 0; x < 3; x++) {       // static indices only (r is a constant after inlining)
             if (x == r) {
-                zm = yl ? blk[0][x][0] : blk[x][0][0]; zz = yl ? blk[1][x][0] : blk[x][1][0]; zp = yl ? blk[2][x][0] : blk[x][2][0];
-                cm = yl ? blk[0][x][1] : blk[x][0][1]; cp = yl ? blk[2][x][1] : blk[x][2][1];
+                zm = yl ? blkR[0][x][0] : blkR[x][0][0]; zp = yl ? blkR[2][x][0] : blkR[x][2][0];
+                cm = yl ? blkR[0][x][1] : blkR[x][0][1]; cp = yl ? blkR[2][x][1] : blkR[x][2][1];
+                by_m = yl ? ry[x][0] : rz[x][0]; by_p = yl ? ry[x][1] : rz[x][1];
             }
         }
-#if PCL_T3_SHARED_RCP
-        const typename RP::BlkRcp &rc = left ? rcL : rcR;
-        Recip by_m, by_p;
-#pragma unroll
-        for (int x = 0; x < 3; x++)
-            if (x == r) { by_m = yl ? rc.y[x][0] : rc.z[x][0]; by_p = yl ? rc.y[x][1] : rc.z[x][1]; }
         const double a1 = by_m.div(-t0);
         const double a2 = by_p.div(t0);
-#else
-        const double a1 = Recip(zm + zz).div(-t0);
-        const double a2 = Recip(zz + zp).div(t0);
-#endif
         om.p = cm * a1 * zm; om.v = -cm * a1;
         op.p = cp * a2 * zp; op.v = cp * a2;
     };
     const P2 zero{0.0, 0.0};
+    // names as in flux3.f; the ...amdq / ...cqxxm ones are those of interface l+1 (the dense code's r_ values)
     P2 bmamdq, bpamdq, bmapdq, bpapdq, cmamdq, cpamdq, cmapdq, cpapdq;
-    split(true, true, 1, amdq[0], bmamdq, bpamdq);
-    split(false, true, 1, apdq[0], bmapdq, bpapdq);
-    split(true, false, 1, amdq[0], cmamdq, cpamdq);
-    split(false, false, 1, apdq[0], cmapdq, cpapdq);
+    split(true, 1, aM, bmamdq, bpamdq);
+    split(true, 1, aP, bmapdq, bpapdq);
+    split(false, 1, aM, cmamdq, cpamdq);
+    split(false, 1, aP, cmapdq, cpapdq);
     P2 bmcqxxm = zero, bpcqxxm = zero, bmcqxxp = zero, bpcqxxp = zero, cmcqxxm = zero, cpcqxxm = zero, cmcqxxp = zero, cpcqxxp = zero;
     if (t.m3 == 2) {
-        split(true, true, 1, cq[0], bmcqxxm, bpcqxxm);
-        split(false, true, 1, cq[0], bmcqxxp, bpcqxxp);
-        split(true, false, 1, cq[0], cmcqxxm, cpcqxxm);
-        split(false, false, 1, cq[0], cmcqxxp, cpcqxxp);
+        split(true, 1, kM, bmcqxxm, bpcqxxm);
+        split(true, 1, kP, bmcqxxp, bpcqxxp);
+        split(false, 1, kM, cmcqxxm, cpcqxxm);
+        split(false, 1, kP, cmcqxxp, cpcqxxp);
     }
     const double k6z = (1.0 / 6.0) * d * t.dtz, k6y = (1.0 / 6.0) * d * t.dty;
-    P2 bmcpapdq = zero, bpcpapdq = zero, bmcpamdq = zero, bpcpamdq = zero, bmcmapdq = zero, bpcmapdq = zero, bmcmamdq = zero, bpcmamdq = zero;
-    // ---- G fluxes (y-like), flux3.f:347-452: the z-like splits (corrected by the correction waves' for m4 = 2) split
-    // again in the y-like direction, inside the z-like row they went to
-    if (t.m4 > 0) {
-        const double cpapdq2 = t.m4 == 2 ? cpapdq.p - 3.0 * cpcqxxp.p : cpapdq.p;
-        const double cpamdq2 = t.m4 == 2 ? cpamdq.p + 3.0 * cpcqxxm.p : cpamdq.p;
-        const double cmapdq2 = t.m4 == 2 ? cmapdq.p - 3.0 * cmcqxxp.p : cmapdq.p;
-        const double cmamdq2 = t.m4 == 2 ? cmamdq.p + 3.0 * cmcqxxm.p : cmamdq.p;
-        split(false, true, 2, cpapdq2, bmcpapdq, bpcpapdq);
-        split(true, true, 2, cpamdq2, bmcpamdq, bpcpamdq);
-        split(false, true, 0, cmapdq2, bmcmapdq, bpcmapdq);
-        split(true, true, 0, cmamdq2, bmcmamdq, bpcmamdq);
-    }
     // one component of the six G (or H) values of this cell: the dense code's statements in their order.
     // b?a?dq: first-level split in the flux's own direction; x???: second-level results; q???: correction-wave splits
     auto six = [&](double k6, double bmap, double bpap, double bmam, double bpam, double xmcpap, double xpcpap, double xmcmap,
                    double xpcmap, double xmcpam, double xpcpam, double xmcmam, double xpcmam, double qmp, double qpp, double qmm,
                    double qpm, double &o10, double &o20, double &o21, double &o11, double &o2m, double &o1m) {
-        const double r_bmam = from_right(bmam), r_bpam = from_right(bpam);
-        const double r_xmcpam = from_right(xmcpam), r_xpcpam = from_right(xpcpam);
-        const double r_xmcmam = from_right(xmcmam), r_xpcmam = from_right(xpcmam);
-        const double r_qmm = from_right(qmm), r_qpm = from_right(qpm);
         double g10 = 0.0, g20 = 0.0, g21 = 0.0, g11 = 0.0, g2m = 0.0, g1m = 0.0;
         g10 = g10 - 0.5 * d * bmap;
         g20 = g20 - 0.5 * d * bpap;
@@ -529,46 +493,61 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
             g20 = g20 + d * qpp;
             g10 = g10 + d * qmp;
         }
-        g10 = g10 - 0.5 * d * r_bmam;
-        g20 = g20 - 0.5 * d * r_bpam;
+        g10 = g10 - 0.5 * d * bmam;                 // interface l+1
+        g20 = g20 - 0.5 * d * bpam;
         if (t.m4 > 0) {
-            g20 = g20 + k6 * (r_xpcpam - r_xpcmam);
-            g10 = g10 + k6 * (r_xmcpam - r_xmcmam);
-            g21 = g21 - k6 * r_xpcpam;
-            g11 = g11 - k6 * r_xmcpam;
-            g2m = g2m + k6 * r_xpcmam;
-            g1m = g1m + k6 * r_xmcmam;
+            g20 = g20 + k6 * (xpcpam - xpcmam);
+            g10 = g10 + k6 * (xmcpam - xmcmam);
+            g21 = g21 - k6 * xpcpam;
+            g11 = g11 - k6 * xmcpam;
+            g2m = g2m + k6 * xpcmam;
+            g1m = g1m + k6 * xmcmam;
         }
         if (t.m3 >= 2) {
-            g20 = g20 - d * r_qpm;
-            g10 = g10 - d * r_qmm;
+            g20 = g20 - d * qpm;
+            g10 = g10 - d * qmm;
         }
         o10 = g10; o20 = g20; o21 = g21; o11 = g11; o2m = g2m; o1m = g1m;
     };
-    six(k6z, bmapdq.p, bpapdq.p, bmamdq.p, bpamdq.p, bmcpapdq.p, bpcpapdq.p, bmcmapdq.p, bpcmapdq.p, bmcpamdq.p, bpcpamdq.p,
-        bmcmamdq.p, bpcmamdq.p, bmcqxxp.p, bpcqxxp.p, bmcqxxm.p, bpcqxxm.p,
-        G[0][1].p, G[1][1].p, G[1][2].p, G[0][2].p, G[1][0].p, G[0][0].p);
-    six(k6z, bmapdq.v, bpapdq.v, bmamdq.v, bpamdq.v, bmcpapdq.v, bpcpapdq.v, bmcmapdq.v, bpcmapdq.v, bmcpamdq.v, bpcpamdq.v,
-        bmcmamdq.v, bpcmamdq.v, bmcqxxp.v, bpcqxxp.v, bmcqxxm.v, bpcqxxm.v,
-        G[0][1].v, G[1][1].v, G[1][2].v, G[0][2].v, G[1][0].v, G[0][0].v);
-    // ---- H fluxes (z-like), flux3.f:462-590: the y-like splits (corrected for m4 = 2) split again in the z-like direction
-    P2 ymcpapdq = zero, ypcpapdq = zero, ymcpamdq = zero, ypcpamdq = zero, ymcmapdq = zero, ypcmapdq = zero, ymcmamdq = zero, ypcmamdq = zero;
-    if (t.m4 > 0) {
-        const double bpapdq2 = t.m4 == 2 ? bpapdq.p - 3.0 * bpcqxxp.p : bpapdq.p;
-        const double bpamdq2 = t.m4 == 2 ? bpamdq.p + 3.0 * bpcqxxm.p : bpamdq.p;
-        const double bmapdq2 = t.m4 == 2 ? bmapdq.p - 3.0 * bmcqxxp.p : bmapdq.p;
-        const double bmamdq2 = t.m4 == 2 ? bmamdq.p + 3.0 * bmcqxxm.p : bmamdq.p;
-        split(false, false, 2, bpapdq2, ymcpapdq, ypcpapdq);
-        split(true, false, 2, bpamdq2, ymcpamdq, ypcpamdq);
-        split(false, false, 0, bmapdq2, ymcmapdq, ypcmapdq);
-        split(true, false, 0, bmamdq2, ymcmamdq, ypcmamdq);
+    {   // ---- G fluxes (y-like), flux3.f:347-452: the z-like splits (corrected by the correction waves' for m4 = 2)
+        // split again in the y-like direction, inside the z-like row they went to
+        P2 bmcpapdq = zero, bpcpapdq = zero, bmcpamdq = zero, bpcpamdq = zero, bmcmapdq = zero, bpcmapdq = zero, bmcmamdq = zero, bpcmamdq = zero;
+        if (t.m4 > 0) {
+            const double cpapdq2 = t.m4 == 2 ? cpapdq.p - 3.0 * cpcqxxp.p : cpapdq.p;
+            const double cpamdq2 = t.m4 == 2 ? cpamdq.p + 3.0 * cpcqxxm.p : cpamdq.p;
+            const double cmapdq2 = t.m4 == 2 ? cmapdq.p - 3.0 * cmcqxxp.p : cmapdq.p;
+            const double cmamdq2 = t.m4 == 2 ? cmamdq.p + 3.0 * cmcqxxm.p : cmamdq.p;
+            split(true, 2, cpapdq2, bmcpapdq, bpcpapdq);
+            split(true, 2, cpamdq2, bmcpamdq, bpcpamdq);
+            split(true, 0, cmapdq2, bmcmapdq, bpcmapdq);
+            split(true, 0, cmamdq2, bmcmamdq, bpcmamdq);
+        }
+        six(k6z, bmapdq.p, bpapdq.p, bmamdq.p, bpamdq.p, bmcpapdq.p, bpcpapdq.p, bmcmapdq.p, bpcmapdq.p, bmcpamdq.p, bpcpamdq.p,
+            bmcmamdq.p, bpcmamdq.p, bmcqxxp.p, bpcqxxp.p, bmcqxxm.p, bpcqxxm.p,
+            G[0][1].p, G[1][1].p, G[1][2].p, G[0][2].p, G[1][0].p, G[0][0].p);
+        six(k6z, bmapdq.v, bpapdq.v, bmamdq.v, bpamdq.v, bmcpapdq.v, bpcpapdq.v, bmcmapdq.v, bpcmapdq.v, bmcpamdq.v, bpcpamdq.v,
+            bmcmamdq.v, bpcmamdq.v, bmcqxxp.v, bpcqxxp.v, bmcqxxm.v, bpcqxxm.v,
+            G[0][1].v, G[1][1].v, G[1][2].v, G[0][2].v, G[1][0].v, G[0][0].v);
     }
-    six(k6y, cmapdq.p, cpapdq.p, cmamdq.p, cpamdq.p, ymcpapdq.p, ypcpapdq.p, ymcmapdq.p, ypcmapdq.p, ymcpamdq.p, ypcpamdq.p,
-        ymcmamdq.p, ypcmamdq.p, cmcqxxp.p, cpcqxxp.p, cmcqxxm.p, cpcqxxm.p,
-        H[0][1].p, H[1][1].p, H[1][2].p, H[0][2].p, H[1][0].p, H[0][0].p);
-    six(k6y, cmapdq.v, cpapdq.v, cmamdq.v, cpamdq.v, ymcpapdq.v, ypcpapdq.v, ymcmapdq.v, ypcmapdq.v, ymcpamdq.v, ypcpamdq.v,
-        ymcmamdq.v, ypcmamdq.v, cmcqxxp.v, cpcqxxp.v, cmcqxxm.v, cpcqxxm.v,
-        H[0][1].v, H[1][1].v, H[1][2].v, H[0][2].v, H[1][0].v, H[0][0].v);
+    {   // ---- H fluxes (z-like), flux3.f:462-590: the y-like splits (corrected for m4 = 2) split again in the z-like direction
+        P2 ymcpapdq = zero, ypcpapdq = zero, ymcpamdq = zero, ypcpamdq = zero, ymcmapdq = zero, ypcmapdq = zero, ymcmamdq = zero, ypcmamdq = zero;
+        if (t.m4 > 0) {
+            const double bpapdq2 = t.m4 == 2 ? bpapdq.p - 3.0 * bpcqxxp.p : bpapdq.p;
+            const double bpamdq2 = t.m4 == 2 ? bpamdq.p + 3.0 * bpcqxxm.p : bpamdq.p;
+            const double bmapdq2 = t.m4 == 2 ? bmapdq.p - 3.0 * bmcqxxp.p : bmapdq.p;
+            const double bmamdq2 = t.m4 == 2 ? bmamdq.p + 3.0 * bmcqxxm.p : bmamdq.p;
+            split(false, 2, bpapdq2, ymcpapdq, ypcpapdq);
+            split(false, 2, bpamdq2, ymcpamdq, ypcpamdq);
+            split(false, 0, bmapdq2, ymcmapdq, ypcmapdq);
+            split(false, 0, bmamdq2, ymcmamdq, ypcmamdq);
+        }
+        six(k6y, cmapdq.p, cpapdq.p, cmamdq.p, cpamdq.p, ymcpapdq.p, ypcpapdq.p, ymcmapdq.p, ypcmapdq.p, ymcpamdq.p, ypcpamdq.p,
+            ymcmamdq.p, ypcmamdq.p, cmcqxxp.p, cpcqxxp.p, cmcqxxm.p, cpcqxxm.p,
+            H[0][1].p, H[1][1].p, H[1][2].p, H[0][2].p, H[1][0].p, H[0][0].p);
+        six(k6y, cmapdq.v, cpapdq.v, cmamdq.v, cpamdq.v, ymcpapdq.v, ypcpapdq.v, ymcmapdq.v, ypcmapdq.v, ymcpamdq.v, ypcpamdq.v,
+            ymcmamdq.v, ypcmamdq.v, cmcqxxp.v, cpcqxxp.v, cmcqxxm.v, cpcqxxm.v,
+            H[0][1].v, H[1][1].v, H[1][2].v, H[0][2].v, H[1][0].v, H[0][0].v);
+    }
 }
 
 // ---- the marching form: no scratch planes ---------------------------------------------------------------------------
