@@ -314,6 +314,44 @@ def timed_run(claw, steps, warmup):
     return elapsed, ms, nl, finite
 
 
+def app_run_object(nxg, nyg, cells_total):
+    """The shock-bubble problem itself on the benchmark grid, from t = 0 to the regression's t = 0.2 (test/euler/2d/
+    shockbubble.py:97-166: inflow / reflecting / outflow sides, adaptive dt at cfl_desired 0.45, radial source term
+    after every step -- fused into the y pass), through solver.evolve_to_time in four quarters of the time interval:
+    the whole-run rate and the rate per quarter, i.e. how the headline (the first steps, mostly undisturbed gas) decays
+    as the shock crosses the bubble and the flow fills the domain."""
+    from pyclaw_amd import _lib
+    claw = build(nxg, nyg, "exact", False, with_src=True)
+    solver, solution = claw.solver, claw.solution
+    solver.setup(solution)
+    solver.dt = solver.dt_initial
+    solver.max_steps = 10 ** 8
+    L = _lib.lib()
+    solver.begin_resident(solution)
+    quarters = []
+    total_steps, total_s = 0, 0.0
+    for k in range(1, 5):
+        _lib.check(L.pcl_sync(solver._h))
+        t0 = time.perf_counter()
+        st = solver.evolve_to_time(solution, 0.05 * k)
+        _lib.check(L.pcl_sync(solver._h))
+        el = time.perf_counter() - t0
+        n = int(st['numsteps'])
+        quarters.append({"t_end": 0.05 * k, "steps": n, "seconds": el, "ms_per_step": el / max(n, 1) * 1e3,
+                         "value": cells_total * n / el / 1e6, "cflmax": float(st['cflmax'])})
+        total_steps += n
+        total_s += el
+    solver.end_resident(solution)
+    finite = bool(np.isfinite(solution.state.q).all())
+    solver.teardown()
+    return {"value": cells_total * total_steps / total_s / 1e6, "unit": "Mcell*steps/s", "steps": total_steps,
+            "seconds": total_s, "ms_per_step": total_s / max(total_steps, 1) * 1e3, "math": "exact",
+            "roofline_frac_whole_step": 160.0 * cells_total * total_steps / total_s / 1e9 / HBM_PEAK_GBS,
+            "what": "apps/euler 2D shock-bubble, t = 0 .. 0.2, adaptive dt (accepted steps counted; rejected ones cost "
+                    "time too), source term on (fused into the y pass), BCs on the device; per quarter of the time interval",
+            "quarters": quarters, "result_finite": finite}
+
+
 def state_object(tag, claw, steps, warmup, cells_total, bytes_launch, describe):
     """K steps of the same solver on another state of the same grid: value + the dominant pass' roofline fraction"""
     el, ms, nl, fin = timed_run(claw, steps, warmup)
@@ -338,6 +376,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-states", action="store_true",
                     help="skip the dense_state / developed_state / sustained objects of the default line")
+    ap.add_argument("--no-app-run", dest="no_app_run", action="store_true",
+                    help="skip the app_run object (the shock-bubble problem from t = 0 to 0.2 on the benchmark grid, ~10 s)")
     ap.add_argument("--state", choices=["bubble", "dense", "developed"], default="bubble",
                     help="state the main timed run starts from (profile runs of the dense / developed state: "
                          "tools/profile_round.sh); anything but bubble implies --no-states")
@@ -530,6 +570,8 @@ def main():
                                  "what": "classic dim-split step + the app's radial source term (Godunov splitting, "
                                          "EulerRadialSource on the device: one more read + write of q per step)",
                                  "result_finite": fin5}
+            if not args.no_app_run:
+                out["app_run"] = app_run_object(nxg, nyg, cells_total)
             if args.steps < 200:
                 # a K-step region of ~10 ms is thin: the same headline state for 1000 steps
                 el4, ms4, nl4, fin4 = timed_run(build(nxg, nyg, "exact", False), 1000, args.warmup)

@@ -249,6 +249,29 @@ template <class RP, int UX, int UY> int launch_unsplit_u(const SweepLaunch &l, c
     } else {
         const int nti = (a.mx + (UY - 2) - 1) / (UY - 2);
         const int ntj = (a.my + STRIP - 1) / STRIP;
+        static const int ymarch = [] { const char *e = getenv("PCL_TUNE_YMARCH"); return e ? atoi(e) : 1; }();
+        if constexpr (RP::NAUX == 0 && UY == 16) {
+            if (ymarch && a.mcapa <= 0 && (a.src_id == 0 || std::is_same<RP, Euler5>::value)) {
+                // marching y phase (classic.hpp: unsplit_ym_kernel): segments of `seg` lines of 16 columns; enough
+                // workgroups for ~4 rounds over the 256 CUs, warm-up step of a segment <= 1/8 of its work
+                const int nlines = (a.mx + 15) / 16;
+                int nseg = (1024 + ntj - 1) / ntj;
+                if (nseg > (nlines + 7) / 8) nseg = (nlines + 7) / 8;
+                if (nseg < 1) nseg = 1;
+                const int seg = (nlines + nseg - 1) / nseg;
+                nseg = (nlines + seg - 1) / seg;
+                if (a.src_id != 0) {
+                    if constexpr (std::is_same<RP, Euler5>::value)
+                        hipLaunchKernelGGL((unsplit_ym_kernel<RP, false, true>), dim3((unsigned)ntj * nseg), dim3(16 * WAVE), 0,
+                                           l.stream, a, ntj, seg, qx);
+                } else
+                    hipLaunchKernelGGL((unsplit_ym_kernel<RP, IsFwave<RP>::value, false>), dim3((unsigned)ntj * nseg),
+                                       dim3(16 * WAVE), 0, l.stream, a, ntj, seg, qx);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return hip_fail(err, "unsplit y (marching) launch", e);
+                return PCL_OK;
+            }
+        }
         if (a.src_id != 0) {       // fused source term: Euler solver without a capacity function
             if constexpr (std::is_same<RP, Euler5>::value) {
                 if (a.src_id != 1 || a.mcapa > 0) { err = "fused source: Euler radial source, no capacity function"; return PCL_EINVAL; }
