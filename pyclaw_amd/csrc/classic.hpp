@@ -1089,12 +1089,15 @@ __global__ __launch_bounds__(U_WAVES *WAVE) void unsplit_y_kernel(SweepArgs a, i
 // segments (one warm-up step each, whose only purpose is the carry) so that the grid still has ~4 workgroups per CU.
 // The combination per cell is the reference's: q6 = ((q3 + gp'(i-1)) + mid(i)) - gm'(i+1)   (step2.f:214-218).
 // Solvers without aux arrays, no capacity function (the others keep unsplit_y_kernel).
-template <class RP, bool FWAVE, bool SRC = false>
-__global__ __launch_bounds__(16 * WAVE) void unsplit_ym_kernel(SweepArgs a, int ntj, int seg, const double *qx) {
+// NWV wavefronts per workgroup, each takes 16 / NWV of the step's 16 slices in turn: 16 (128 VGPRs per lane: the Euler
+// core spills ~29 of them) or 8 (256 VGPRs, no spills, two slices per wavefront and step).
+template <class RP, bool FWAVE, bool SRC = false, int NWV = 16>
+__global__ __launch_bounds__(NWV *WAVE) void unsplit_ym_kernel(SweepArgs a, int ntj, int seg, const double *qx) {
     // slots 2..17: this step's slices; the carry (slices 14, 15 of the previous step) sits in slots 0, 1 or 18, 19 in turn,
     // so that a step can write the next carry while its own is still being read
-    constexpr int MEQN = RP::MEQN, UW = 16, NS = UW + 4;
+    constexpr int MEQN = RP::MEQN, UW = 16, NS = UW + 4, SPW = UW / NWV, NT = NWV * WAVE;
     static_assert(RP::NAUX == 0, "solvers without aux arrays");
+    static_assert(UW % NWV == 0, "16 slices per step");
     __shared__ double tile[MEQN][WAVE][NS + 1];                    // qold columns in, then each slice's own increment "mid"
     __shared__ double gp[NS][MEQN][WAVE], gm[UW][MEQN][WAVE];
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
@@ -1106,9 +1109,12 @@ __global__ __launch_bounds__(16 * WAVE) void unsplit_ym_kernel(SweepArgs a, int 
     double cflmax = 0.0;
     for (int T = L0 - 1; T < L1; T++) {
         const int c0 = a.mbc + UW * T + 1;                         // first computed column; finished: c0-1 .. c0+14
-        {   // cooperative load of qold: 16 lanes per row segment (one column past the line boundary: two lines per row,
-            // the second one is the next step's first)
-            const int c = threadIdx.x % UW, r = threadIdx.x / UW;
+        // cooperative load of qold: 16 lanes per row segment (one column past the line boundary: two lines per row,
+        // the second one is the next step's first)
+#pragma unroll
+        for (int k = 0; k < UW * WAVE / NT; k++) {
+            const int id = threadIdx.x + k * NT;
+            const int c = id % UW, r = id / UW;
             int gi = c0 + c, gj = j0 + r;
             gi = gi < 0 ? 0 : (gi < a.I ? gi : a.I - 1);
             gj = gj < a.J ? gj : a.J - 1;
@@ -1117,49 +1123,58 @@ __global__ __launch_bounds__(16 * WAVE) void unsplit_ym_kernel(SweepArgs a, int 
             for (int m = 0; m < MEQN; m++) tile[m][r][c + 2] = a.qin[m * a.plane + g];
         }
         __syncthreads();
-        const int col = c0 + w;
-        const bool slice_ok = col >= a.mbc - 1 && col <= a.mbc + a.mx;      // slices 0 .. mx+1 (wave-uniform)
-        if (slice_ok && !(T < L0 && w < UW - 2)) {                  // the warm-up step only needs its last two slices
-            double q[MEQN], qadd[MEQN], df[MEQN], g1[MEQN], g2[MEQN];
+#pragma unroll 1
+        for (int k = 0; k < SPW; k++) {
+            const int sl = w + NWV * k;                             // this wavefront's slice of the step
+            const int col = c0 + sl;
+            const bool slice_ok = col >= a.mbc - 1 && col <= a.mbc + a.mx;      // slices 0 .. mx+1 (wave-uniform)
+            if (slice_ok && !(T < L0 && sl < UW - 2)) {             // the warm-up step only needs its last two slices
+                double q[MEQN], qadd[MEQN], df[MEQN], g1[MEQN], g2[MEQN];
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) q[m] = tile[m][lane][w + 2];
-            const bool cfl_ok = (cj >= a.mbc) && (cj <= a.mbc + a.my) && lane >= 1;
-            lane_core<RP, 2, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2);
+                for (int m = 0; m < MEQN; m++) q[m] = tile[m][lane][sl + 2];
+                const bool cfl_ok = (cj >= a.mbc) && (cj <= a.mbc + a.my) && lane >= 1;
+                lane_core<RP, 2, false, FWAVE, false, true>(q, a.dtd, 1.0, cfl_ok, a, qadd, cflmax, df, g1, g2);
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) {
-                gm[w][m][lane] = a.dtd_t * g1[m];
-                gp[w + 2][m][lane] = a.dtd_t * g2[m];
-                tile[m][lane][w + 2] = qadd[m] - a.dtd * df[m] - a.dtd_t * (g2[m] - g1[m]);   // only this wave reads column w
+                for (int m = 0; m < MEQN; m++) {
+                    gm[sl][m][lane] = a.dtd_t * g1[m];
+                    gp[sl + 2][m][lane] = a.dtd_t * g2[m];
+                    tile[m][lane][sl + 2] = qadd[m] - a.dtd * df[m] - a.dtd_t * (g2[m] - g1[m]);   // only this wave reads the column
+                }
             }
         }
         __syncthreads();
         const int cin = ((T - (L0 - 1)) & 1) ? UW + 2 : 0, cout = cin ? 0 : UW + 2;       // carry slots read / written by this step
-        if (w >= UW - 2 && T + 1 < L1) {   // carry: slices 14, 15 go to the next step (nobody reads `cout` during this step)
+        if (w >= NWV - 2 && T + 1 < L1) {   // carry: slices 14, 15 go to the next step (nobody reads `cout` during this step)
+            const int sl = UW - 2 + (w - (NWV - 2));
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
-                gp[cout + w - (UW - 2)][m][lane] = gp[w + 2][m][lane];
-                tile[m][lane][cout + w - (UW - 2)] = tile[m][lane][w + 2];
+                gp[cout + sl - (UW - 2)][m][lane] = gp[sl + 2][m][lane];
+                tile[m][lane][cout + sl - (UW - 2)] = tile[m][lane][sl + 2];
             }
         }
         if (T >= L0) {   // finish the line: column c0-1+c = the previous step's last slice (c = 0) or this step's slice c-1
-            const int c = threadIdx.x % UW, r = threadIdx.x / UW;
-            const int gi = c0 - 1 + c, gj = j0 + r;
-            const bool ok = gi >= a.mbc && gi < a.mbc + a.mx && r >= HALO && r < WAVE - HALO && gj >= a.mbc && gj < a.mbc + a.my;
-            if (ok) {
-                const long g = (long)gj * a.pitch + gi;
-                double v[MEQN];
 #pragma unroll
-                for (int m = 0; m < MEQN; m++) {
-                    double x = qx[m * a.plane + g] + gp[c < 2 ? cin + c : c][m][r];     // from slice i-1 = column c0-2+c
-                    x = x + tile[m][r][c < 1 ? cin + 1 : c + 1];                        // the slice's own increment
-                    v[m] = x - gm[c][m][r];                                             // from slice i+1 (this step's slice c)
-                }
-                if constexpr (SRC) {
-                    static_assert(!SRC || MEQN == 5, "fused source: Euler solver");
-                    euler_radial_source(v[0], v[1], v[2], v[3], a.aux[g], a.dt, a.src_p[0], a.src_p[1]);
-                }
+            for (int k = 0; k < UW * WAVE / NT; k++) {
+                const int id = threadIdx.x + k * NT;
+                const int c = id % UW, r = id / UW;
+                const int gi = c0 - 1 + c, gj = j0 + r;
+                const bool ok = gi >= a.mbc && gi < a.mbc + a.mx && r >= HALO && r < WAVE - HALO && gj >= a.mbc && gj < a.mbc + a.my;
+                if (ok) {
+                    const long g = (long)gj * a.pitch + gi;
+                    double v[MEQN];
 #pragma unroll
-                for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = v[m];
+                    for (int m = 0; m < MEQN; m++) {
+                        double x = qx[m * a.plane + g] + gp[c < 2 ? cin + c : c][m][r];     // from slice i-1 = column c0-2+c
+                        x = x + tile[m][r][c < 1 ? cin + 1 : c + 1];                        // the slice's own increment
+                        v[m] = x - gm[c][m][r];                                             // from slice i+1 (this step's slice c)
+                    }
+                    if constexpr (SRC) {
+                        static_assert(!SRC || MEQN == 5, "fused source: Euler solver");
+                        euler_radial_source(v[0], v[1], v[2], v[3], a.aux[g], a.dt, a.src_p[0], a.src_p[1]);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = v[m];
+                }
             }
         }
         __syncthreads();       // the next step's load overwrites slots 2..17

@@ -260,12 +260,20 @@ template <class RP, int UX, int UY> int launch_unsplit_u(const SweepLaunch &l, c
                 if (nseg < 1) nseg = 1;
                 const int seg = (nlines + nseg - 1) / nseg;
                 nseg = (nlines + seg - 1) / seg;
+                // wavefronts per workgroup: 8 (two slices each per step, 256 VGPRs: no spills) for the register-heavy
+                // Euler core, 16 for the small systems; PCL_TUNE_YMARCH=16 / 8 forces one
+                constexpr bool heavy = RP::MEQN >= 5;
+                const bool eight = ymarch == 8 || (ymarch != 16 && heavy);
                 if (a.src_id != 0) {
-                    if constexpr (std::is_same<RP, Euler5>::value)
-                        hipLaunchKernelGGL((unsplit_ym_kernel<RP, false, true>), dim3((unsigned)ntj * nseg), dim3(16 * WAVE), 0,
-                                           l.stream, a, ntj, seg, qx);
-                } else
-                    hipLaunchKernelGGL((unsplit_ym_kernel<RP, IsFwave<RP>::value, false>), dim3((unsigned)ntj * nseg),
+                    if constexpr (std::is_same<RP, Euler5>::value) {
+                        if (eight) hipLaunchKernelGGL((unsplit_ym_kernel<RP, false, true, 8>), dim3((unsigned)ntj * nseg), dim3(8 * WAVE), 0, l.stream, a, ntj, seg, qx);
+                        else hipLaunchKernelGGL((unsplit_ym_kernel<RP, false, true, 16>), dim3((unsigned)ntj * nseg), dim3(16 * WAVE), 0, l.stream, a, ntj, seg, qx);
+                    }
+                } else if (eight)
+                    hipLaunchKernelGGL((unsplit_ym_kernel<RP, IsFwave<RP>::value, false, 8>), dim3((unsigned)ntj * nseg),
+                                       dim3(8 * WAVE), 0, l.stream, a, ntj, seg, qx);
+                else
+                    hipLaunchKernelGGL((unsplit_ym_kernel<RP, IsFwave<RP>::value, false, 16>), dim3((unsigned)ntj * nseg),
                                        dim3(16 * WAVE), 0, l.stream, a, ntj, seg, qx);
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) return hip_fail(err, "unsplit y (marching) launch", e);
