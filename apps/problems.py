@@ -220,7 +220,7 @@ def acoustics2D(pyclaw, mx=100, my=100, tfinal=0.12, nout=10, dim_split=1, run=T
 
 
 def acoustics1D(pyclaw, mx=100, solver_type='classic', lim_type=2, time_integrator='SSP104', weno_order=5,
-                math='exact'):
+                math='exact', char_decomp=0):
     """test/acoustics/1d/homogeneous/acoustics.py: returns the one-period L1 error."""
     if solver_type == 'classic':
         solver = pyclaw.ClawSolver1D()
@@ -229,6 +229,7 @@ def acoustics1D(pyclaw, mx=100, solver_type='classic', lim_type=2, time_integrat
         solver.lim_type = lim_type
         solver.time_integrator = time_integrator
         solver.weno_order = weno_order
+        solver.char_decomp = char_decomp
     solver.math = math
     solver.rp = pyclaw.riemann.rp_acoustics_1d
     x = pyclaw.Dimension('x', 0.0, 1.0, mx)

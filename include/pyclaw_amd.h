@@ -187,6 +187,13 @@ int pcl_step3(int rp, const double *rp_params, int meqn, int mwaves, int maux, i
 /* clawparams.mthlim, part of the F90 module state the reference sets before calling flux1/flux2
  * (sharpclaw.py:268); read by lim_type = 1 (tvd2) only, indexed by component.  Default: all 1 (minmod). */
 int pcl_sharp_module_mthlim(const int *mthlim, int n);
+/* clawparams.char_decomp of the same module state (sharpclaw.py:262), read by pcl_sharp_flux1: 0 = component-wise
+ * reconstruction, 1 = wave-based (1d/sharpclaw/flux1.f90:80-107: rp1 on the cell averages, then tvd2_wave for
+ * lim_type 1 -- mthlim indexed by WAVE there -- or weno5_wave for lim_type 2; reconstruct.f90:393-478,728-806).
+ * 2 and 3 need a user-supplied evec routine the reference only stubs (evec.f90:13-14), and the 2-D flux1.f90 calls
+ * rpn2 with a wrong argument list on the char_decomp = 1 path (2d/sharpclaw/flux1.f90:86): neither can run in the
+ * reference, neither is offered.  A resident solver takes the value in cfg.method[4] (method(5), unused by SharpClaw). */
+int pcl_sharp_module_char_decomp(int char_decomp);
 int pcl_sharp_flux1(int rp, const double *rp_params, int lim_type, int meqn, int mwaves, int maux, int mcapa,
                     int mbc, int mx, const double *q, double *dq, const double *aux, double dx, double dt,
                     double *cfl);

@@ -283,6 +283,10 @@ def sharp_dq(p, backend, q, t):
     fill_ghosts(p.qbc, mbc, p.bc_lower, p.bc_upper, p.user_bc_lower, p.user_bc_upper, t)
     if hasattr(backend, "set_weno_order"):
         backend.set_weno_order(p.weno_order)               # clawparams.weno_order (sharpclaw.py:263)
+    if hasattr(backend, "set_char_decomp"):                # clawparams.char_decomp / mthlim (sharpclaw.py:262,268)
+        backend.set_char_decomp(getattr(p, "char_decomp", 0))
+        if getattr(p, "char_decomp", 0) == 1 or p.lim_type == 1:
+            backend.set_sharp_mthlim(p.mthlim)
     if p.ndim == 1:
         dq, cfl = backend.sharp_flux1(p.rp, p.rp_params, p.lim_type, p.mwaves, p.mcapa + 1, mbc, q.shape[1],
                                       p.qbc, p.auxbc, p.d[0], p.dt)

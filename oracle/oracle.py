@@ -204,6 +204,24 @@ class COracle:
         m = np.ascontiguousarray(mthlim, dtype=np.int32)
         self.lib.orc_sharp_set_mthlim(_i(m), len(m))
 
+    def set_char_decomp(self, char_decomp, fwave=False):
+        """clawparams.char_decomp / fwave (sharpclaw.py:262-266): 1 = wave-based reconstruction in the 1-D flux1"""
+        self.lib.orc_sharp_set_char_decomp(int(char_decomp), int(bool(fwave)))
+
+    def recon_wave(self, kind, q, wave, s, mthlim):
+        """tvd2_wave (kind 1) / weno5_wave (2) / weno5_fwave (3) of 1d/sharpclaw/reconstruct.f90 on given arrays
+        q (meqn, n), wave (meqn, mwaves, n), s (mwaves, n); indices outside the arrays read as 0 -> (ql, qr)"""
+        meqn, n = q.shape
+        mwaves = wave.shape[1]
+        q = np.asfortranarray(q, dtype=np.float64)
+        w = np.array(wave, dtype=np.float64, order="F")
+        s = np.asfortranarray(s, dtype=np.float64)
+        ql = np.zeros((meqn, n), order="F")
+        qr = np.zeros((meqn, n), order="F")
+        m = np.ascontiguousarray(mthlim, dtype=np.int32)
+        assert self.lib.orc_recon_wave(int(kind), meqn, mwaves, n, _d(q), _d(w), _d(s), _i(m), _d(ql), _d(qr)) == 0
+        return ql, qr
+
     def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt):
         """sharpclaw2.flux2(q,aux,dt,t,mbc,maxm,mx,my) -> (dq,cfl)  (sharpclaw.py:558)"""
         meqn = q.shape[0]
@@ -402,6 +420,25 @@ class RefSharp2DEuler:
     @staticmethod
     def available():
         return os.path.exists(os.path.join(_HERE, "_ref", "libref_sharpclaw2d_euler.so"))
+
+    def recon_wave(self, kind, q, wave, s, mthlim, pad=4):
+        """the reference's own tvd2_wave / weno5_wave / weno5_fwave (oracle/ref_sharpclaw_shim.f90: sc_recon_wave).  The
+        Fortran reads up to two entries outside its arrays: they are handed views into zero-padded buffers, so those
+        reads see 0 (what the C restatement assumes).  Call before any sharp_flux2 of the process (shim comment)."""
+        meqn, n = q.shape
+        mwaves = wave.shape[1]
+        N = n + 2 * pad
+        qb = np.zeros((meqn, N), order="F"); qb[:, pad:pad + n] = q
+        wb = np.zeros((meqn, mwaves, N), order="F"); wb[:, :, pad:pad + n] = wave
+        sb = np.ones((mwaves, N), order="F"); sb[:, pad:pad + n] = s
+        qlb = np.zeros((meqn, N), order="F"); qrb = np.zeros((meqn, N), order="F")
+        m = np.ascontiguousarray(mthlim, dtype=np.int32)
+        v = lambda a, k: a[(slice(None),) * k + (slice(pad, pad + n),)]
+        qv, wv, sv, qlv, qrv = v(qb, 1), v(wb, 2), v(sb, 1), v(qlb, 1), v(qrb, 1)
+        assert qv.flags.f_contiguous and wv.flags.f_contiguous and sv.flags.f_contiguous
+        self.lib.sc_recon_wave(C.c_int(kind), C.c_int(meqn), C.c_int(mwaves), C.c_int(n), _d(qv), _d(qlv), _d(qrv), _d(wv),
+                               _d(sv), _i(m))
+        return np.array(qlv, order="F"), np.array(qrv, order="F")
 
     def sharp_flux2(self, rp, par, lim_type, mwaves, mcapa, mbc, mx, my, q, aux, dx, dy, dt, mthlim=None,
                     weno_order=5):

@@ -213,6 +213,139 @@ static void tvd2(const double *q, double *ql, double *qr, int meqn, int n)
     }
 }
 
+/* ---- char_decomp = 1: wave-based reconstructions (1d/sharpclaw/reconstruct.f90) ------------------------------------
+ * q (meqn, n), wave (meqn, mwaves, n), s (mwaves, n), Fortran order, 1-based second / third index.  The Fortran loops
+ * run over every interface i = 2..n and read wave(:,:,i-2..i+2) and q(:,i-2..i+1): the first and last ones reach
+ * outside the arrays (reconstruct.f90:411-470; harmless for the interior, mbc = 3).  Here an index outside 1..n reads
+ * 0 -- the golden generator pads its arrays with zeros accordingly -- so results agree at EVERY index.
+ * REAL*4 literals (7., 12., 13., 3., 6., 0.5, 0.25, 1./..., 1.e-14, epweno = 1.e-36) are promoted from float. */
+static int orc_char_decomp = 0, orc_sharp_fwave = 0;
+void orc_sharp_set_char_decomp(int cd, int fwave) { orc_char_decomp = cd; orc_sharp_fwave = fwave; }
+#define WV(m, mw, i) (((i) < 1 || (i) > n) ? 0.0 : wave[(m) + meqn * ((mw) + (size_t)mwaves * ((i)-1))])
+#define QZ(m, i) (((i) < 1 || (i) > n) ? 0.0 : q[(m) + meqn * ((i)-1)])
+#define SV(mw, i) s[(mw) + mwaves * ((i)-1)]
+
+/* reconstruct.f90:393-478 (fw = 0) and :481-565 (fw = 1; the caller has divided the f-waves by s) */
+static void weno5_wave(const double *q, double *ql, double *qr, const double *wave, int meqn, int mwaves, int n, int fw)
+{
+    const double epweno = (double)1.e-36f, tol = (double)1.e-14f;
+    for (int i = 2; i <= n; i++) {
+        for (int m = 0; m < meqn; m++) {
+            if (fw) { QR(m, i - 1) = QZ(m, i - 1); QL(m, i) = QZ(m, i); }
+            else {
+                QR(m, i - 1) = (-QZ(m, i - 2) + 7. * (QZ(m, i - 1) + QZ(m, i)) - QZ(m, i + 1)) / 12.;
+                QL(m, i) = QR(m, i - 1);
+            }
+        }
+        for (int mw = 0; mw < mwaves; mw++) {
+            double u[2], wnorm2 = 0.0;
+            for (int m1 = 1; m1 <= 2; m1++) {
+                const int im = (m1 == 1) ? 1 : -1;
+                const int ione = im, inone = -im, intwo = -2 * im;
+                double theta1, theta2, theta3;
+                wnorm2 = WV(0, mw, i) * WV(0, mw, i);
+                theta1 = WV(0, mw, i + intwo) * WV(0, mw, i);
+                theta2 = WV(0, mw, i + inone) * WV(0, mw, i);
+                theta3 = WV(0, mw, i + ione) * WV(0, mw, i);
+                for (int m = 1; m < meqn; m++) {
+                    wnorm2 = wnorm2 + WV(m, mw, i) * WV(m, mw, i);
+                    theta1 = theta1 + WV(m, mw, i + intwo) * WV(m, mw, i);
+                    theta2 = theta2 + WV(m, mw, i + inone) * WV(m, mw, i);
+                    theta3 = theta3 + WV(m, mw, i + ione) * WV(m, mw, i);
+                }
+                const double t1 = im * (theta1 - theta2);
+                const double t2 = im * (theta2 - wnorm2);
+                const double t3 = im * (wnorm2 - theta3);
+                double a, tt1, tt2, tt3;
+                a = theta1 - 3. * theta2; tt1 = 13. * (t1 * t1) + 3. * (a * a);
+                a = theta2 + wnorm2;      tt2 = 13. * (t2 * t2) + 3. * (a * a);
+                a = 3. * wnorm2 - theta3; tt3 = 13. * (t3 * t3) + 3. * (a * a);
+                a = epweno + tt1; tt1 = a * a;
+                a = epweno + tt2; tt2 = a * a;
+                a = epweno + tt3; tt3 = a * a;
+                double s1 = tt2 * tt3;
+                const double s2 = 6. * tt1 * tt3;
+                double s3 = 3. * tt1 * tt2;
+                const double t0 = 1. / (s1 + s2 + s3);
+                s1 = s1 * t0;
+                s3 = s3 * t0;
+                if (wnorm2 > tol) {
+                    if (fw)
+                        u[m1 - 1] = ((s1 * (t2 - t1) + (0.5 * s3 - 0.25) * (t3 - t2)) / 3. +
+                                     im * (theta2 + 6.0 * wnorm2 - theta3) / 12.0);
+                    else
+                        u[m1 - 1] = (s1 * (t2 - t1) + (0.5 * s3 - 0.25) * (t3 - t2)) / 3.;
+                    wnorm2 = 1.0 / wnorm2;
+                } else {
+                    u[m1 - 1] = 0.0;
+                    wnorm2 = 0.0;
+                }
+            }
+            for (int m = 0; m < meqn; m++) {
+                QR(m, i - 1) = QR(m, i - 1) + u[0] * WV(m, mw, i) * wnorm2;
+                QL(m, i) = QL(m, i) + u[1] * WV(m, mw, i) * wnorm2;
+            }
+        }
+    }
+}
+
+/* reconstruct.f90:728-806; its local mbc is 2: interfaces i = 2 .. n-2 */
+static void tvd2_wave(const double *q, double *ql, double *qr, const double *wave, const double *s, const int *mthlim,
+                      int meqn, int mwaves, int n)
+{
+    for (int i = 2; i <= n; i++)
+        for (int m = 0; m < meqn; m++) { QR(m, i - 1) = Q(m, i - 1); QL(m, i) = Q(m, i); }
+    for (int mw = 0; mw < mwaves; mw++) {
+        double dotr = 0.0;
+        for (int i = 2; i <= n - 2; i++) {
+            double wnorm2 = 0.0;
+            const double dotl = dotr;
+            dotr = 0.0;
+            for (int m = 0; m < meqn; m++) {
+                wnorm2 = wnorm2 + WV(m, mw, i) * WV(m, mw, i);
+                dotr = dotr + WV(m, mw, i) * WV(m, mw, i + 1);
+            }
+            if (wnorm2 == 0.0) continue;
+            const double r = (SV(mw, i) > 0.0) ? dotl / wnorm2 : dotr / wnorm2;
+            double wlimitr = 0.0;
+            switch (mthlim[mw]) {
+            case 1: wlimitr = fmax(0.0, fmin(1.0, r)); break;
+            case 2: wlimitr = fmax(fmax(0.0, fmin(1.0, 2.0 * r)), fmin(2.0, r)); break;
+            case 3: wlimitr = (r + fabs(r)) / (1.0 + fabs(r)); break;
+            case 4: { const double c = (1.0 + r) / 2.0; wlimitr = fmax(0.0, fmin(fmin(c, 2.0), 2.0 * r)); break; }
+            case 5: {
+                const double beta = 2.0, xgamma = 2.0, alpha = 1.0 / 3.0;
+                const double pp = (2.0 + r) / 3.0;
+                const double amax = fmax(fmax(-alpha * r, 0.0), fmin(fmin(beta * r, pp), xgamma));
+                wlimitr = fmax(0.0, fmin(pp, amax));
+                break;
+            }
+            }
+            const double uu = 0.5 * wlimitr;
+            for (int m = 0; m < meqn; m++) {
+                QR(m, i - 1) = QR(m, i - 1) + WV(m, mw, i) * uu;
+                QL(m, i) = QL(m, i) - WV(m, mw, i) * uu;
+            }
+        }
+    }
+}
+
+/* direct entry (goldens of the reconstructions themselves): kind 1 tvd2_wave, 2 weno5_wave, 3 weno5_fwave (wave /= s first) */
+int orc_recon_wave(int kind, int meqn, int mwaves, int n, const double *q, double *wave, const double *s, const int *mthlim,
+                   double *ql, double *qr)
+{
+    if (kind == 1) tvd2_wave(q, ql, qr, wave, s, mthlim, meqn, mwaves, n);
+    else if (kind == 2) weno5_wave(q, ql, qr, wave, meqn, mwaves, n, 0);
+    else if (kind == 3) {
+        for (int i = 1; i <= n; i++)
+            for (int mw = 0; mw < mwaves; mw++)
+                for (int m = 0; m < meqn; m++)
+                    wave[m + meqn * (mw + (size_t)mwaves * (i - 1))] = wave[m + meqn * (mw + (size_t)mwaves * (i - 1))] / SV(mw, i);
+        weno5_wave(q, ql, qr, wave, meqn, mwaves, n, 1);
+    } else return -1;
+    return 0;
+}
+
 /* flux1.f90:59-188 on one slice.  q1d (meqn, 1-mbc:mx+mbc); dq1d same extent, returned. */
 static int flux1(int ndim, int rp, const double *par, int lim_type, int ixy, int meqn, int mwaves, int mbc,
                  int mx, const double *q1d, double *dq1d, const double *dtdx, double *cfl_out, double *work)
@@ -224,7 +357,20 @@ static int flux1(int ndim, int rp, const double *par, int lim_type, int ixy, int
     memset(work, 0, sizeof(double) * ((size_t)meqn * n * 6 + (size_t)meqn * mwaves * n + (size_t)mwaves * n));
     const double *q = q1d;
     /* the Fortran indexes the slice 1..maxnx+2mbc inside weno: i_weno = i_cell + mbc */
-    if (lim_type == 1)
+    if (orc_char_decomp == 1) {
+        /* 1d/sharpclaw/flux1.f90:80-107: rp1 on (q1d, q1d), then the waves as slopes */
+        if (ndim != 1 || (lim_type != 1 && lim_type != 2)) return -4;
+        int rcw = orc_rp1_ptr(rp, par, meqn, mwaves, mbc, mx, q, q, wave, s, amdq, apdq);
+        if (rcw) return rcw;
+        if (lim_type == 1) tvd2_wave(q, ql, qr, wave, s, orc_tvd_mthlim, meqn, mwaves, n);
+        else if (orc_sharp_fwave) {
+            for (int i = 1; i <= n; i++)
+                for (int mw = 0; mw < mwaves; mw++)
+                    for (int m = 0; m < meqn; m++)
+                        wave[m + meqn * (mw + (size_t)mwaves * (i - 1))] /= s[mw + mwaves * (i - 1)];
+            weno5_wave(q, ql, qr, wave, meqn, mwaves, n, 1);
+        } else weno5_wave(q, ql, qr, wave, meqn, mwaves, n, 0);
+    } else if (lim_type == 1)
         tvd2(q, ql, qr, meqn, n);
     else if (lim_type == 2 && orc_weno_order == 5)
         weno5_pyweno(q, ql, qr, meqn, n, 3, n - 2);     /* every index whose 5-point stencil is in range */

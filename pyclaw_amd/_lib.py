@@ -62,6 +62,7 @@ PROTOTYPES = {
     "pcl_step3ds": (C.c_int, [C.c_int, dp] + [C.c_int] * 7 + [dp, dp, dp] + [C.c_double] * 4 + [ip, ip, dp, C.c_int]),
     "pcl_step3": (C.c_int, [C.c_int, dp] + [C.c_int] * 7 + [dp, dp, dp] + [C.c_double] * 4 + [ip, ip, dp]),
     "pcl_sharp_module_mthlim": (C.c_int, [ip, C.c_int]),
+    "pcl_sharp_module_char_decomp": (C.c_int, [C.c_int]),
     "pcl_sharp_flux1": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   dp, dp, dp, C.c_double, C.c_double, dp]),
     "pcl_sharp_flux2": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

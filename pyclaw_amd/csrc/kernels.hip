@@ -409,8 +409,34 @@ template <class RP, int IXY, bool HIGH = false> int launch_sharp_t(const SweepLa
 }
 }  // namespace
 
+namespace {
+template <class RP> int launch_sharp1w(const SweepLaunch &l, std::string &err) {
+    const SweepArgs &a = l.a;
+    const int nstrips = (a.mx + sstrip(3) - 1) / sstrip(3);
+    const dim3 grid((unsigned)((nstrips + 3) / 4));
+    if (l.lim_type == 1) hipLaunchKernelGGL((sharp1w_kernel<RP, 1>), grid, dim3(256), 0, l.stream, a, nstrips);
+    else hipLaunchKernelGGL((sharp1w_kernel<RP, 2>), grid, dim3(256), 0, l.stream, a, nstrips);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "sharp (wave-based) launch", e);
+}
+}  // namespace
+
 int launch_sharp(const SweepLaunch &l, std::string &err) {
     const int rp = l.rp;
+    if (l.char_decomp == 1) {
+        // 1d/sharpclaw/flux1.f90:80-107 (the 2-D flux1.f90 calls rpn2 with a wrong argument list there and cannot run)
+        if (l.ndim != 1 || l.a.mbc != 3 || (l.lim_type != 1 && l.lim_type != 2) || l.a.mcapa > 0 || l.a.src_id != 0) {
+            err = "SharpClaw char_decomp = 1: 1-D, lim_type 1 (tvd2_wave) or 2 (weno5_wave), mbc 3, no capacity function";
+            return PCL_EINVAL;
+        }
+        if (rp == PCL_RP_ADVECTION_1D) return launch_sharp1w<Advection1D>(l, err);
+        if (rp == PCL_RP_ACOUSTICS_1D) return launch_sharp1w<Acoustics1D>(l, err);
+        if (rp == PCL_RP_BURGERS_1D) return launch_sharp1w<Burgers1D>(l, err);
+        if (rp == PCL_RP_EULER_1D) return launch_sharp1w<Euler1D>(l, err);
+        if (rp == PCL_RP_SHALLOW_1D) return launch_sharp1w<Shallow1D>(l, err);
+        err = "SharpClaw char_decomp = 1: Riemann solvers without aux arrays (advection, acoustics, Burgers, Euler, shallow water in 1-D)";
+        return PCL_EINVAL;
+    }
     if (l.ndim == 1) {
         if (rp == PCL_RP_ADVECTION_1D) return launch_sharp_t<Advection1D, 1, true>(l, err);
         if (rp == PCL_RP_ACOUSTICS_1D) return launch_sharp_t<Acoustics1D, 1, true>(l, err);

@@ -668,6 +668,15 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (cfg->kind != PCL_KIND_CLASSIC && cfg->kind != PCL_KIND_SHARPCLAW) return fail(PCL_EINVAL, "unknown solver kind");
     if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->lim_type != 1 && cfg->lim_type != 2 && cfg->lim_type != 3)
         return fail(PCL_EINVAL, "SharpClaw: lim_type must be 1 (tvd2), 2 (WENO5) or 3 (legacy WENO5)");
+    if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->method[4] != 0) {
+        // char_decomp (sharpclaw.py:262): 1 = wave-based reconstruction, 1-D only (the reference's 2-D flux1.f90 calls rpn2
+        // with a wrong argument list on that path, 2d/sharpclaw/flux1.f90:86); 2 and 3 need a user-supplied evec routine
+        // the reference only stubs (evec.f90:13-14)
+        if (cfg->method[4] != 1) return fail(PCL_EINVAL, "SharpClaw: char_decomp must be 0 or 1 (2, 3 need a user evec routine)");
+        if (cfg->ndim != 1 || cfg->mbc != 3 || (cfg->lim_type != 1 && cfg->lim_type != 2) || cfg->method[5] != 0 || cfg->fwave)
+            return fail(PCL_EINVAL, "SharpClaw char_decomp = 1: 1-D, lim_type 1 (tvd2_wave) or 2 (weno5_wave), weno_order 5, "
+                                    "no capacity function, no f-wave solver");
+    }
     if (cfg->kind == PCL_KIND_SHARPCLAW && cfg->lim_type == 1 && cfg->meqn > PCL_MAX_WAVES)
         return fail(PCL_EINVAL, "SharpClaw tvd2: mthlim is indexed by component, meqn <= PCL_MAX_WAVES");
     if (cfg->mwaves < 1 || cfg->mwaves > PCL_MAX_WAVES) return fail(PCL_EINVAL, "bad mwaves");
@@ -1338,6 +1347,7 @@ static int sharp_pass(pcl_solver *s, int ids, double dt, int rk_op, const double
     }
     l.ndim = s->cfg.ndim; l.rp = s->cfg.rp; l.ids = ids; l.fwave = s->cfg.fwave;
     l.lim_type = s->cfg.lim_type; l.stream = stream;
+    l.char_decomp = s->cfg.method[4];          // SharpClaw: clawparams.char_decomp travels in method(5) (unused by it)
     pcl_solver::Timed t{};
     if (timing_on(s)) { t.a = get_event(s); t.b = get_event(s); t.which = ids - 1; t.count = sub != 2; hipEventRecord(t.a, stream); }
     int rc = PCL_BY_MATH(s->cfg.math, launch_sharp(l, err));
@@ -1582,7 +1592,7 @@ bool same_shape(const pcl_config &a, const pcl_config &b) {
     return a.ndim == b.ndim && a.n[0] == b.n[0] && a.n[1] == b.n[1] && a.n[2] == b.n[2] && a.mbc == b.mbc &&
            a.meqn == b.meqn && a.mwaves == b.mwaves && a.maux == b.maux && a.rp == b.rp && a.kind == b.kind &&
            a.device == b.device && a.math == b.math && a.lim_type == b.lim_type && a.fwave == b.fwave &&
-           a.method[5] == b.method[5] && (a.method[2] < 0) == (b.method[2] < 0);
+           a.method[5] == b.method[5] && (a.method[2] < 0) == (b.method[2] < 0) && a.method[4] == b.method[4];
 }
 // a handle for this configuration: the cached one (its scalars refreshed) or a new one that replaces it
 int g_l1_math = PCL_MATH_EXACT;     // arithmetic mode of the f2py-shaped calls (pcl_layer1_math)
@@ -1711,6 +1721,15 @@ int pcl_step3ds(int rp, const double *rp_params, int meqn, int mwaves, int maux,
 // clawparams.mthlim of the F90 module state (sharpclaw.py:268): only lim_type = 1 (tvd2) reads it
 static int g_sharp_mthlim[PCL_MAX_WAVES] = {1, 1, 1, 1, 1, 1, 1, 1};
 
+// clawparams.char_decomp of the F90 module state (sharpclaw.py:262): read by pcl_sharp_flux1
+static int g_sharp_char_decomp = 0;
+int pcl_sharp_module_char_decomp(int char_decomp) {
+    if (char_decomp != 0 && char_decomp != 1) return fail(PCL_EINVAL, "pcl_sharp_module_char_decomp: 0 or 1");
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
+    g_sharp_char_decomp = char_decomp;
+    return PCL_OK;
+}
+
 int pcl_sharp_module_mthlim(const int *mthlim, int n) {
     if (!mthlim || n < 0 || n > PCL_MAX_WAVES) return fail(PCL_EINVAL, "pcl_sharp_module_mthlim: 0 <= n <= PCL_MAX_WAVES");
     std::lock_guard<std::mutex> lock(g_l1_mutex);
@@ -1753,6 +1772,7 @@ static int host_sharp(int ndim, int rp, const double *rp_params, int lim_type, i
     memset(&c, 0, sizeof(c));
     c.ndim = ndim; c.n[0] = mx; c.n[1] = my; c.mbc = mbc; c.meqn = meqn; c.mwaves = mwaves; c.maux = maux;
     c.method[1] = 2; c.method[5] = mcapa; c.method[6] = maux;
+    c.method[4] = ndim == 1 ? g_sharp_char_decomp : 0;
     for (int k = 0; k < PCL_MAX_WAVES; k++) c.mthlim[k] = g_sharp_mthlim[k];
     c.rp = rp;
     if (rp_params) for (int k = 0; k < PCL_MAX_RP_PARAMS; k++) c.rp_params[k] = rp_params[k];

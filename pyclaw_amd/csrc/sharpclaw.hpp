@@ -401,6 +401,187 @@ __global__ __launch_bounds__(256, CAPA ? 3 : PCL_SHARP_OCC) void sharp_kernel(Sw
     cfl_publish(a.cfl, cflmax);
 }
 
+// ---- char_decomp = 1 in 1-D: wave-based reconstruction (1d/sharpclaw/flux1.f90:80-107) -------------------------------
+// flux1 first solves the Riemann problems between the cell averages (rp1 on q1d, q1d) and hands the waves to tvd2_wave
+// (lim_type 1, reconstruct.f90:728-806) or weno5_wave (lim_type 2, :393-478), which build the two states of every
+// INTERFACE from them: q^-(i-1/2) = qr(i-1) and q^+(i-1/2) = ql(i).  One lane = one cell = the interface on its left:
+// lane l solves (l-1, l), fetches the waves of the interfaces l-2, l-1, l+1, l+2 by DPP shifts, builds qm = qr(l-1) and
+// qp = ql(l), solves the interface problem (qm, qp) and the problem inside the cell (qp, the right lane's qm).  Halo 3
+// like WENO5: lanes 3..60 are stored.  Solvers without aux arrays, no capacity function.  Operation order of
+// oracle/sharpclaw_oracle.c: weno5_wave / tvd2_wave (== the reference's Fortran bit for bit, tests/golden/ref_recon_wave.npz).
+template <int MEQN>
+__device__ __forceinline__ double dot_m(const double (&a)[MEQN], const double (&b)[MEQN]) {
+    double d = a[0] * b[0];
+#pragma unroll
+    for (int m = 1; m < MEQN; m++) d = d + a[m] * b[m];
+    return d;
+}
+// one wave family of weno5_wave: the waves at interfaces i-2 .. i+2 -> the coefficients u(1), u(2) and 1/|w|^2 (or 0)
+template <int MEQN>
+__device__ __forceinline__ void weno5_wave_family(const double (&wm2)[MEQN], const double (&wm1)[MEQN], const double (&w0)[MEQN],
+                                                  const double (&wp1)[MEQN], const double (&wp2)[MEQN], double &u1, double &u2,
+                                                  double &winv) {
+    const double epweno = PCL_F32(1.e-36), tol = PCL_F32(1.e-14);
+    double u[2], wnorm2 = 0.0;
+#pragma unroll
+    for (int m1 = 0; m1 < 2; m1++) {
+        const double im = m1 == 0 ? 1.0 : -1.0;
+        wnorm2 = dot_m<MEQN>(w0, w0);
+        const double theta1 = m1 == 0 ? dot_m<MEQN>(wm2, w0) : dot_m<MEQN>(wp2, w0);     // i + intwo
+        const double theta2 = m1 == 0 ? dot_m<MEQN>(wm1, w0) : dot_m<MEQN>(wp1, w0);     // i + inone
+        const double theta3 = m1 == 0 ? dot_m<MEQN>(wp1, w0) : dot_m<MEQN>(wm1, w0);     // i + ione
+        const double t1 = im * (theta1 - theta2), t2 = im * (theta2 - wnorm2), t3 = im * (wnorm2 - theta3);
+        double x, tt1, tt2, tt3;
+        x = theta1 - 3. * theta2; tt1 = 13. * (t1 * t1) + 3. * (x * x);
+        x = theta2 + wnorm2;      tt2 = 13. * (t2 * t2) + 3. * (x * x);
+        x = 3. * wnorm2 - theta3; tt3 = 13. * (t3 * t3) + 3. * (x * x);
+        x = epweno + tt1; tt1 = x * x;
+        x = epweno + tt2; tt2 = x * x;
+        x = epweno + tt3; tt3 = x * x;
+        double s1 = tt2 * tt3;
+        const double s2 = 6. * tt1 * tt3;
+        double s3 = 3. * tt1 * tt2;
+        const double t0 = fdiv_ieee(1.0, s1 + s2 + s3);
+        s1 = s1 * t0;
+        s3 = s3 * t0;
+        if (wnorm2 > tol) {
+            u[m1] = fdiv_ieee(s1 * (t2 - t1) + (0.5 * s3 - 0.25) * (t3 - t2), 3.0);
+            wnorm2 = fdiv_ieee(1.0, wnorm2);
+        } else {
+            u[m1] = 0.0;
+            wnorm2 = 0.0;
+        }
+    }
+    u1 = u[0]; u2 = u[1]; winv = wnorm2;
+}
+// the limiter of tvd2_wave (reconstruct.f90:771-793): philim's 1..4 and Cada & Torrilhon's (5)
+__device__ __forceinline__ double tvd2_wave_limiter(double r, int meth) {
+    switch (meth) {
+    case 1: return dmax(0.0, dmin(1.0, r));
+    case 2: return dmax(dmax(0.0, dmin(1.0, 2.0 * r)), dmin(2.0, r));
+    case 3: return fdiv_ieee(r + fabs(r), 1.0 + fabs(r));
+    case 4: { const double c = (1.0 + r) / 2.0; return dmax(0.0, dmin(dmin(c, 2.0), 2.0 * r)); }
+    case 5: {
+        const double alpha = fdiv_ieee(1.0, 3.0);
+        const double pp = fdiv_ieee(2.0 + r, 3.0);
+        const double amax = dmax(dmax(-alpha * r, 0.0), dmin(dmin(2.0 * r, pp), 2.0));
+        return dmax(0.0, dmin(pp, amax));
+    }
+    }
+    return 0.0;
+}
+
+template <class RP, int LIM>
+__global__ __launch_bounds__(256) void sharp1w_kernel(SweepArgs a, int nstrips) {
+    constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES, SH = 3, SS = sstrip(SH);
+    static_assert(RP::NAUX == 0, "wave-based reconstruction: solvers without aux arrays");
+    static_assert(LIM == 1 || LIM == 2, "tvd2_wave / weno5_wave");
+    using Cell = typename RP::Cell;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int strip = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+    if (strip >= nstrips) return;                         // wave-uniform (no barrier in this kernel)
+    const int a0 = a.mbc - SH + strip * SS;
+    const int ca = a0 + lane;
+    const int cc = ca < a.I ? ca : a.I - 1;
+    const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.mx) && lane >= SH && lane < WAVE - SH;
+    const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.mx) && lane >= SH && lane <= WAVE - SH;
+    double q[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) q[m] = a.qin[m * a.plane + cc];
+    // rp1(q1d, q1d): the waves between the cell averages, interface `lane` = (lane-1, lane)
+    const Cell c0 = RP::template precell<1>(q, a.par);
+    const Cell cm = struct_from_left(c0);
+    double w0[MWAVES][MEQN], s0[MWAVES], t_am[MEQN], t_ap[MEQN];
+    RP::template solve<1>(cm, c0, a.par, w0, s0, t_am, t_ap);
+    double qm[MEQN], qp[MEQN];
+    const double qm1c = 0.0;
+    (void)qm1c;
+    double ql1[MEQN];            // the left cell's average
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) ql1[m] = from_left(q[m]);
+    if constexpr (LIM == 2) {
+        // stencil-independent part (reconstruct.f90:415-418): (-q(i-2) + 7 (q(i-1) + q(i)) - q(i+1)) / 12
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) {
+            const double qm2 = from_left(ql1[m]), qp1 = from_right(q[m]);
+            qm[m] = fdiv_ieee(-qm2 + 7. * (ql1[m] + q[m]) - qp1, 12.0);
+            qp[m] = qm[m];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) { qm[m] = ql1[m]; qp[m] = q[m]; }
+    }
+#pragma unroll
+    for (int mw = 0; mw < MWAVES; mw++) {
+        double wm1[MEQN], wp1[MEQN];
+#pragma unroll
+        for (int m = 0; m < MEQN; m++) { wm1[m] = from_left(w0[mw][m]); wp1[m] = from_right(w0[mw][m]); }
+        if constexpr (LIM == 2) {
+            double wm2[MEQN], wp2[MEQN], u1, u2, winv;
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) { wm2[m] = from_left(wm1[m]); wp2[m] = from_right(wp1[m]); }
+            weno5_wave_family<MEQN>(wm2, wm1, w0[mw], wp1, wp2, u1, u2, winv);
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                qm[m] = qm[m] + u1 * w0[mw][m] * winv;
+                qp[m] = qp[m] + u2 * w0[mw][m] * winv;
+            }
+        } else {
+            // tvd2_wave: dotl = w(i-1).w(i), dotr = w(i).w(i+1), sums started from 0.d0 (same values)
+            const double wnorm2 = dot_m<MEQN>(w0[mw], w0[mw]);
+            const double dotr = dot_m<MEQN>(w0[mw], wp1);
+            const double dotl = dot_m<MEQN>(wm1, w0[mw]);
+            if (wnorm2 != 0.0) {
+                const double r = fdiv_ieee(s0[mw] > 0.0 ? dotl : dotr, wnorm2);
+                const double uu = 0.5 * tvd2_wave_limiter(r, a.mthlim[mw]);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) {
+                    qm[m] = qm[m] + w0[mw][m] * uu;
+                    qp[m] = qp[m] - w0[mw][m] * uu;
+                }
+            }
+        }
+    }
+    // interface problem (qr(i-1), ql(i)) and the problem inside the cell (ql(i), qr(i)): flux1.f90:125-187
+    const Cell em = RP::template precell<1>(qm, a.par), ep = RP::template precell<1>(qp, a.par);
+    double wave[MWAVES][MEQN], s[MWAVES], amdq[MEQN], apdq[MEQN], amdq2[MEQN], apdq2[MEQN];
+    RP::template solve<1>(em, ep, a.par, wave, s, amdq, apdq);
+    double cflmax = 0.0;
+    if (cfl_ok) {
+#pragma unroll
+        for (int mw = 0; mw < MWAVES; mw++) cflmax = dmax(dmax(cflmax, a.dtd * s[mw]), -a.dtd * s[mw]);
+    }
+    double qmr[MEQN];
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) qmr[m] = from_right(qm[m]);          // qr(i) = the right lane's q^-
+    const Cell er = RP::template precell<1>(qmr, a.par);
+    RP::template solve<1>(ep, er, a.par, wave, s, amdq2, apdq2);
+    const Recip by_ca(a.rk_op == 1 ? a.rk_ca : 1.0);
+#pragma unroll
+    for (int m = 0; m < MEQN; m++) {      // the shift must run with every lane active
+        const double amdq_r = from_right(amdq[m]);
+        const double dq = -(a.dtd * (amdq_r + apdq[m] + amdq2[m] + apdq2[m]));
+        if (owned) {
+            const long at = m * a.plane + cc;
+            double r = dq;
+            if (a.rk_op != 0) {       // the RK combination fused into the (only) pass: sharp_kernel's store phase
+                const double av = a.rk_a[at], bv = a.rk_b[at];
+                double quo = by_ca.div(dq);
+#if !PCL_FAST
+                if (a.rk_op == 1 && __builtin_fabs(dq) < 0x1p-900 && dq != 0.0) { asm volatile(""); quo = dq / a.rk_ca; }
+#endif
+                const double r1 = av + quo;
+                const double r2 = a.rk_ca * av + a.rk_cb * (bv + dq);
+                const double r5 = av + a.rk_cb * bv + a.rk_cc * dq;
+                r = a.rk_op == 1 ? r1 : (a.rk_op == 2 ? r2 : r5);
+            }
+            double *dst = a.rk_op != 0 ? a.rk_d : a.qout;
+            dst[at] = r;
+        }
+    }
+    cfl_publish(a.cfl, cflmax);
+}
+
 // ---- Runge-Kutta register arithmetic (sharpclaw.py:168-206), elementwise over whole arrays ----------
 struct RkOp {
     double *d;

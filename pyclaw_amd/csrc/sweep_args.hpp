@@ -135,6 +135,7 @@ struct SweepLaunch {
     int ids;    // 1 = x pass (or the 1-D step), 2 = y pass
     int fwave;
     int lim_type;  // SharpClaw reconstruction (2 PyWENO weno5, 3 legacy weno5)
+    int char_decomp = 0;   // SharpClaw: 1 = wave-based reconstruction (1-D: tvd2_wave / weno5_wave)
     hipStream_t stream;
 };
 

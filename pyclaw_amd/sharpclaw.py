@@ -267,8 +267,14 @@ class SharpClawSolver(Solver):
             raise NotImplementedError("weno_order > 5 is a lim_type=2 (PyWENO) reconstruction")
         if self.lim_type not in (1, 2, 3):
             raise NotImplementedError("pyclaw_amd SharpClaw implements lim_type 1 (tvd2), 2 (WENO5) and 3 (legacy WENO5)")
-        if self.char_decomp != 0 or self.tfluct_solver:
-            raise NotImplementedError("pyclaw_amd SharpClaw implements char_decomp=0, tfluct_solver=False")
+        if self.tfluct_solver:
+            raise NotImplementedError("pyclaw_amd SharpClaw implements tfluct_solver=False (the reference's tfluct.f90 is a stub)")
+        if self.char_decomp not in (0, 1):
+            raise NotImplementedError("char_decomp 2 / 3 need a user-supplied evec routine (the reference only stubs evec.f90)")
+        if self.char_decomp == 1 and (self.ndim != 1 or self.lim_type not in (1, 2) or self.weno_order != 5 or self.fwave):
+            # 1d/sharpclaw/flux1.f90:80-107; the 2-D flux1.f90 calls rpn2 with a wrong argument list on this path
+            raise NotImplementedError("char_decomp=1 (wave-based reconstruction): 1-D solvers, lim_type 1 (tvd2_wave) or "
+                                      "2 (weno5_wave), weno_order 5, no f-wave solver")
         if self.time_integrator not in ('Euler', 'SSP33', 'SSP104'):
             raise Exception('Unrecognized time integrator')
         self.mbc = (self.weno_order + 1) // 2
@@ -293,6 +299,7 @@ class SharpClawSolver(Solver):
         cfg.mwaves = self.mwaves
         cfg.maux = state.maux
         cfg.method[1] = 2
+        cfg.method[4] = int(self.char_decomp)          # clawparams.char_decomp (sharpclaw.py:262)
         cfg.method[5] = state.mcapa + 1
         cfg.method[6] = state.maux
         for k, m in enumerate(self.mthlim[:_lib.MAX_WAVES]):      # clawparams.mthlim (sharpclaw.py:268): tvd2 reads it

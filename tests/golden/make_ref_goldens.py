@@ -10,6 +10,7 @@ under /root/reference, oracle/Makefile) for the paths the reference ships no gol
   ref_sharp_tvd2.npz       SharpClaw flux2.f90 with lim_type 1 (tvd2), mthlim 1..5
   ref_sharp_weno_orders.npz  SharpClaw flux2.f90 with lim_type 2 and weno_order 7, 9, ..., 17 (weno.f90)
   ref_flux2fw.npz          flux2fw.f (the classic2fw link of step2ds.f / step2.f): dim-split x / y, unsplit trans 0/1/2
+  ref_recon_wave.npz       tvd2_wave / weno5_wave / weno5_fwave of 1d/sharpclaw/reconstruct.f90 (char_decomp = 1)
   ref_sphere_setup.npz     the shallow-sphere app's own setaux.f / qinit.f / src2.f / qcor.f (40 x 20 grid)
 
 Only inputs' SEEDS and the outputs are stored (inputs are regenerated from the seed by the tests).  Run in the
@@ -66,7 +67,33 @@ PAR = [1.4, 0.4]
 MTH = [4, 4, 4, 4, 2]
 
 
+def recon_wave_inputs(kind, lim):
+    """q, wave, s for the wave-based reconstructions: a smooth profile with a jump, waves that partly vanish (the
+    wnorm2 <= 1e-14 and wnorm2 == 0 branches), speeds of both signs"""
+    rng = np.random.default_rng(900 + 10 * kind + lim)
+    meqn, mwaves, n = 3, 3, 46
+    x = np.arange(n) / float(n)
+    q = np.asfortranarray(np.stack([1.0 + 0.3 * np.sin(6.0 * x) + (x > 0.6), 0.2 * rng.random(n) - 0.1, 2.0 + 0.1 * rng.standard_normal(n)]))
+    wave = np.asfortranarray(0.3 * rng.standard_normal((meqn, mwaves, n)))
+    wave[:, 1, 10:14] = 0.0                       # a family without a wave
+    wave[:, 2, 20:23] *= 1e-9                     # |wave|^2 below the 1e-14 switch of weno5_wave
+    s = np.asfortranarray(rng.standard_normal((mwaves, n)))
+    s = np.where(np.abs(s) < 0.05, 0.05, s)       # weno5_fwave divides by s
+    return q, wave, np.asfortranarray(s)
+
+
 def main():
+    # ---- char_decomp = 1: the wave-based reconstructions, FIRST (shim comment at sc_recon_wave)
+    srw = O.RefSharp2DEuler()
+    out = {}
+    for kind, lims in ((1, (1, 2, 3, 4, 5)), (2, (0,)), (3, (0,))):
+        for lim in lims:
+            q, wave, s = recon_wave_inputs(kind, lim)
+            ql, qr = srw.recon_wave(kind, q, wave, s, [max(lim, 1)] * 3)
+            out["ql_kind%d_lim%d" % (kind, lim)] = ql
+            out["qr_kind%d_lim%d" % (kind, lim)] = qr
+    np.savez_compressed(os.path.join(HERE, "ref_recon_wave.npz"), **out)
+
     ref = O.RefEuler2D()
     mx, my, mbc = 37, 26, 2
     shape = (mx + 2 * mbc, my + 2 * mbc)

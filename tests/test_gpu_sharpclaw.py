@@ -174,3 +174,87 @@ def test_f2py_shaped_flux2(coracle):
     inner = (slice(None), slice(mbc, -mbc), slice(mbc, -mbc))
     assert np.array_equal(dq[inner], ref[inner]) and cfl.value == cfl_ref
     assert np.count_nonzero(dq[:, :mbc]) == 0
+
+
+# ---- char_decomp = 1: wave-based reconstruction in 1-D (1d/sharpclaw/flux1.f90:80-107) ---------------------------------
+def state_1d(rp, rng, n):
+    if rp == O.RP_EULER_1D:
+        rho = 1 + 0.3 * rng.random(n); u = 0.6 * (rng.random(n) - .5); p = 1 + 0.3 * rng.random(n)
+        rho[n // 2:] *= 0.4                            # a contact / shock
+        return np.asfortranarray(np.stack([rho, rho * u, p / 0.4 + 0.5 * rho * u * u])), [1.4, 0.4]
+    if rp == O.RP_SHALLOW_1D:
+        h = 1 + 0.3 * rng.random(n); h[n // 3:] += 0.5
+        return np.asfortranarray(np.stack([h, h * 0.4 * (rng.random(n) - .5)])), [9.81]
+    if rp == O.RP_ACOUSTICS_1D:
+        q = rng.standard_normal((2, n)); q[:, n // 4:n // 4 + 9] = 0.25       # a constant stretch: waves of zero norm
+        return np.asfortranarray(q), [1.0, 4.0, 2.0, 2.0]
+    if rp == O.RP_BURGERS_1D:
+        return np.asfortranarray(rng.standard_normal((1, n))), []
+    return np.asfortranarray(rng.standard_normal((1, n))), [0.7]              # advection
+
+
+@pytest.mark.parametrize("rp,meqn,mwaves", [(O.RP_ADVECTION_1D, 1, 1), (O.RP_ACOUSTICS_1D, 2, 2), (O.RP_BURGERS_1D, 1, 1),
+                                             (O.RP_EULER_1D, 3, 3), (O.RP_SHALLOW_1D, 2, 2)])
+@pytest.mark.parametrize("lim,mth", [(2, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 5)])
+@pytest.mark.parametrize("mx", [57, 58, 59, 333])
+def test_flux1_wave_based_bitexact(coracle, rp, meqn, mwaves, lim, mth, mx):
+    """pcl_sharp_flux1 with the module state char_decomp = 1 (pcl_sharp_module_char_decomp) == the oracle's flux1 with
+    rp1(q, q) + tvd2_wave (lim_type 1, mthlim per WAVE) / weno5_wave (lim_type 2), bit for bit, Courant number included;
+    strip boundaries at 58 cells."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(1000 * rp + mx + lim)
+    mbc = 3
+    q, par = state_1d(rp, rng, mx + 2 * mbc)
+    dx, dt = 1.0 / mx, 0.2 / mx
+    coracle.set_char_decomp(1)
+    coracle.set_sharp_mthlim([mth] * mwaves)
+    try:
+        ref, cfl_ref = coracle.sharp_flux1(rp, par + [0.0] * (8 - len(par)), lim, mwaves, 0, mbc, mx, q, None, dx, dt)
+    finally:
+        coracle.set_char_decomp(0)
+        coracle.set_sharp_mthlim([1] * 8)
+    dq = np.zeros_like(q)
+    cfl = C.c_double()
+    L.check(lib.pcl_sharp_module_char_decomp(1))
+    L.check(lib.pcl_sharp_module_mthlim(L.i(np.array([mth] * mwaves, dtype=np.int32)), mwaves))
+    try:
+        L.check(lib.pcl_sharp_flux1(rp, L.d(np.array(par + [0.0] * (8 - len(par)))), lim, meqn, mwaves, 0, 0, mbc, mx, L.d(q),
+                                    L.d(dq), None, dx, dt, C.cast(C.byref(cfl), L.dp)))
+    finally:
+        L.check(lib.pcl_sharp_module_char_decomp(0))
+        L.check(lib.pcl_sharp_module_mthlim(L.i(np.ones(8, dtype=np.int32)), 8))
+    assert np.isfinite(ref[:, mbc:-mbc]).all() and np.abs(ref[:, mbc:-mbc]).max() > 0
+    assert np.array_equal(dq[:, mbc:-mbc], ref[:, mbc:-mbc]), np.abs(dq - ref)[:, mbc:-mbc].max()
+    assert cfl.value == cfl_ref
+
+
+@pytest.mark.parametrize("lim,ti", [(2, 'SSP104'), (1, 'SSP104')])
+def test_acoustics1d_wave_based_replay(coracle, lim, ti):
+    """SharpClawSolver1D with char_decomp = 1 through evolve_to_time (fused Runge-Kutta stages) == the oracle driver's
+    replay of the same run, bit for bit; the one-period error stays at the component-wise scheme's level"""
+    import pyclaw_amd as pyclaw
+    err, claw = problems.acoustics1D(pyclaw, solver_type='sharpclaw', lim_type=lim, time_integrator=ti, char_decomp=1)
+    kw = dict(cfl_max=2.5, cfl_desired=2.45) if ti == 'SSP104' else dict(cfl_max=2.5, cfl_desired=2.45)
+    p = D.acoustics1d_problem(solver_type='sharpclaw', lim_type=lim, time_integrator=ti, char_decomp=1, **kw)
+    D.run(p, coracle, 1.0, 5)
+    coracle.set_char_decomp(0)
+    assert np.array_equal(claw.frames[5].state.q, p.q), np.abs(claw.frames[5].state.q - p.q).max()
+    assert err < (5e-2 if lim == 1 else 5e-3), err
+
+
+def test_char_decomp_refusals():
+    import pyclaw_amd as pyclaw
+    from pyclaw_amd import _lib as L
+    s2 = pyclaw.SharpClawSolver2D()
+    s2.char_decomp = 1
+    s2.rp = pyclaw.riemann.rp_acoustics_2d
+    s2.mwaves = 2
+    with pytest.raises(NotImplementedError):
+        s2.setup(None)
+    for cd in (2, 3):
+        s1 = pyclaw.SharpClawSolver1D()
+        s1.char_decomp = cd
+        with pytest.raises(NotImplementedError):
+            s1.setup(None)
+    assert L.lib().pcl_sharp_module_char_decomp(2) != 0

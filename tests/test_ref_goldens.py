@@ -104,6 +104,19 @@ def test_oracle_flux2fw_form(coracle, which):
     assert not np.array_equal(qn, plain)          # the f-wave form really is a different formula
 
 
+@pytest.mark.parametrize("kind,lim", [(1, 1), (1, 2), (1, 3), (1, 4), (1, 5), (2, 0), (3, 0)])
+def test_oracle_wave_based_reconstructions(coracle, kind, lim):
+    """char_decomp = 1: tvd2_wave (kind 1, every limiter of its select case incl. Cada-Torrilhon), weno5_wave (2) and
+    weno5_fwave (3) of 1d/sharpclaw/reconstruct.f90, called in the reference's own flang build on seeded arrays
+    (oracle/ref_sharpclaw_shim.f90: sc_recon_wave; out-of-array reads of the Fortran loops see zero padding): the C
+    restatement reproduces ql and qr at EVERY index, bit for bit."""
+    z = load("ref_recon_wave.npz")
+    q, wave, s = G.recon_wave_inputs(kind, lim)
+    ql, qr = coracle.recon_wave(kind, q, wave, s, [max(lim, 1)] * 3)
+    assert np.array_equal(ql, z["ql_kind%d_lim%d" % (kind, lim)]) and np.array_equal(qr, z["qr_kind%d_lim%d" % (kind, lim)])
+    assert np.isfinite(ql).all() and not np.array_equal(ql[:, 4:-4], q[:, 4:-4])
+
+
 @pytest.mark.parametrize("mth", [1, 2, 3, 4, 5])
 def test_oracle_sharp_tvd2(coracle, mth):
     """lim_type = 1 (tvd2, reconstruct.f90:568-625).  Cells of the first interior row / column are left out: there the
