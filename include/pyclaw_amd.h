@@ -221,7 +221,7 @@ int pcl_bc_const(pcl_solver *s, int idim, int side, const double *state /* [meqn
 int pcl_bc_aux(pcl_solver *s, int idim, int side, int bctype);
 /* Copy the `width` outermost layers (ghost cells first) of one side to/from a host
  * array shaped like qbc with that dimension cut to `width`: for custom BCs written in
- * Python that only touch the strip (user_bc_lower/upper, solver.py:404-405,439-440). */
+ * Python that only touch the strip (user_bc_lower/upper, solver.py:404-405,439-440).  1-D, 2-D and 3-D. */
 int pcl_get_strip(pcl_solver *s, int idim, int side, int width, double *host);
 int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *host);
 /* the aux twin of pcl_put_strip: a ghost strip of auxbc filled by a Python aux-BC callback (user_aux_bc_lower/upper,
@@ -229,7 +229,7 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
 int pcl_put_aux_strip(pcl_solver *s, int idim, int side, int width, const double *host);
 /* Gauges (Solver.write_gauge_values, solver.py:731-741: q[:,x,y] and aux[:,x,y] of a few cells
  * after every step): gather `ncell` interior cells (0-based interior indices ij[2*c], ij[2*c+1];
- * the second is ignored in 1-D) of the resident q -- and of aux when `aux` is not NULL -- into
+ * the second is ignored in 1-D; on a 3-D grid the tuples are triples ij[3*c], ij[3*c+1], ij[3*c+2]) of the resident q -- and of aux when `aux` is not NULL -- into
  * q[ncell][meqn] / aux[ncell][maux].  One small kernel + one D2H of ncell*(meqn+maux) doubles
  * instead of reading the whole state back every step. */
 int pcl_get_cells(pcl_solver *s, int ncell, const int *ij, double *q, double *aux);

@@ -1190,9 +1190,11 @@ __global__ __launch_bounds__(NWV *WAVE) void unsplit_ym_kernel(SweepArgs a, int 
 // as [al][ac] with pitch 17 (coalesced 128-byte row segments in, conflict-free column reads out).
 // Slices are swept only for transverse indices 0..m+1 (one ghost layer, step3ds.f:110-111,176-177,245-246);
 // every other cell is copied through, so the output array is complete.
-template <class RP, int DIR>
+// CAPA: capacity function aux(mcapa) (step3ds.f:138-141,196-200: dtdx1d = dtdx / capa per cell, the correction-flux
+// difference of the update divided by the cell's capa); it rides in the tile as one more plane.
+template <class RP, int DIR, bool CAPA = false>
 __global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac, int ntiles_al) {
-    constexpr int MEQN = RP::MEQN, NAUX = RP::NAUX, NP = MEQN + NAUX;
+    constexpr int MEQN = RP::MEQN, NAUX = RP::NAUX, NP = MEQN + NAUX + (CAPA ? 1 : 0);
     // DIR 1 (along i): 4 rows x 244 cells, each wavefront walks the 4 strips of its row: 240 updated cells =
     // 15 whole lines per row, like the 2-D x pass.  DIR 2, 3: 64 cells along x 16 columns, one strip per column.
     constexpr int NSTRIP = DIR == 1 ? 4 : 1;
@@ -1222,6 +1224,7 @@ __global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac,
         for (int m = 0; m < MEQN; m++) tile[at(m, al, ac)] = ld_stream(&a.qin[m * a.plane + g]);
 #pragma unroll
         for (int m = 0; m < NAUX; m++) tile[at(MEQN + m, al, ac)] = a.aux[aux_idx<RP, DIR>(m) * a.plane + g];
+        if constexpr (CAPA) tile[at(MEQN + NAUX, al, ac)] = a.aux[(long)(a.mcapa - 1) * a.plane + g];
     };
     if (DIR == 1) {
         if ((int)threadIdx.x < ALONG) {
@@ -1246,13 +1249,14 @@ __global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac,
     double cflmax = 0.0;
     // strips of one row (DIR 1) overlap by 2*HALO cells in the tile and results go back in place: the next
     // strip's cells are read before this strip's results are written (LDS keeps a wavefront's order)
-    double q[MEQN], auxv[NAUX > 0 ? NAUX : 1];
+    double q[MEQN], auxv[NAUX > 0 ? NAUX : 1], capa = 1.0;
     bool have = false;
     auto fetch = [&](int u) {
 #pragma unroll
         for (int m = 0; m < MEQN; m++) q[m] = tile[at(m, unit_al(u), unit_ac(u))];
 #pragma unroll
         for (int m = 0; m < NAUX; m++) auxv[m] = tile[at(MEQN + m, unit_al(u), unit_ac(u))];
+        if constexpr (CAPA) capa = tile[at(MEQN + NAUX, unit_al(u), unit_ac(u))];
     };
 #pragma unroll
     for (int u = 0; u < UNITS; u++) {
@@ -1263,8 +1267,8 @@ __global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac,
         const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.m_al) && lane >= 1;
         if (!have) fetch(u);
         double qn[MEQN];
-        lane_core<RP, DIR, false, false, false, false, true>(q, a.dtd, 1.0, cfl_ok, a, qn, cflmax, nullptr, nullptr,
-                                                             nullptr, auxv);
+        lane_core<RP, DIR, CAPA, false, false, false, true>(q, CAPA ? a.dtd / capa : a.dtd, capa, cfl_ok, a, qn, cflmax, nullptr,
+                                                            nullptr, nullptr, auxv);
         have = unit_live(u + 1);
         if (have) fetch(u + 1);  // issued ahead of the writes below
         if (owned) {
@@ -1304,7 +1308,7 @@ __global__ __launch_bounds__(256) void sweep3_kernel(SweepArgs a, int ntiles_ac,
             if (inner ? (al >= HALO && al < ALONG - HALO) : true) put(al, threadIdx.x % AC);
         }
     }
-    cfl_publish(a.cfl, cfl_value<false>(cflmax, a.dtd));
+    cfl_publish(a.cfl, cfl_value<CAPA>(cflmax, a.dtd));
 }
 
 }  // namespace PCL_NS

@@ -115,12 +115,15 @@ int launch_sweep3(const SweepLaunch &l, std::string &err) {
     const SweepArgs &a = l.a;
     if (l.fwave) { err = "fwave: no 3-D f-wave Riemann solver is built in"; return PCL_EINVAL; }
     if (l.rp != PCL_RP_VC_ACOUSTICS_3D) { err = "Riemann solver id is not a 3-D solver"; return PCL_EINVAL; }
-    if (a.mcapa > 0) { err = "3-D sweeps: capacity function not implemented"; return PCL_EINVAL; }
     const int n_ac = l.ids == 1 ? a.n_ac : a.n_ac + (LINE - a.mbc);  // y, z: columns counted from the line boundary
     const int ac = l.ids == 1 ? 4 : 16, adv = l.ids == 1 ? 4 * STRIP : STRIP;   // tile shape, classic.hpp
     const int ntiles_ac = (n_ac + ac - 1) / ac, ntiles_al = (a.m_al + adv - 1) / adv;
     const dim3 grid((unsigned)ntiles_ac * (unsigned)ntiles_al, (unsigned)a.n_b);
-    if (l.ids == 1) hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 1>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
+    if (a.mcapa > 0) {      // capacity function (step3ds.f:138-141,196-200)
+        if (l.ids == 1) hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 1, true>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
+        else if (l.ids == 2) hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 2, true>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
+        else hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 3, true>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
+    } else if (l.ids == 1) hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 1>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
     else if (l.ids == 2) hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 2>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
     else hipLaunchKernelGGL((sweep3_kernel<VcAcoustics3D, 3>), grid, dim3(256), 0, l.stream, a, ntiles_ac, ntiles_al);
     hipError_t e = hipGetLastError();

@@ -731,7 +731,9 @@ int pcl_create(const pcl_config *cfg, pcl_solver **out) {
     if (cfg->ndim == 3) {
         if (cfg->kind != PCL_KIND_CLASSIC) return fail(PCL_EINVAL, "3-D: classic solver only (the reference has no 3-D SharpClaw)");
         if (cfg->maux < 2) return fail(PCL_EINVAL, "rpn3_vc_acoustics needs aux(1)=impedance, aux(2)=sound speed");
-        if (cfg->method[5] != 0) return fail(PCL_EINVAL, "3-D: capacity function not implemented");
+        if (cfg->method[5] != 0 && cfg->method[2] >= 0)
+            return fail(PCL_EINVAL, "3-D: the capacity function is built for the dimension-split step (step3ds); the unsplit step3 "
+                                    "with mcapa is not");
     }
     if (int rc = check_device()) return rc;
     HIP_TRY(hipSetDevice(cfg->device));
@@ -867,29 +869,30 @@ int pcl_get_q(pcl_solver *s, double *host, int with_ghosts) {
     return PCL_OK;
 }
 
-static int strip_window(pcl_solver *s, int idim, int side, int width, int &ni, int &nj, int &io,
-                        int &jo) {
-    if (s->cfg.ndim > 2) return fail(PCL_EINVAL, "custom-BC strips are implemented for 1-D/2-D");
+// window of a ghost strip: `width` layers of side `side` of dimension idim, the whole ghosted extent in the others
+struct StripWin { int ni, nj, nk, io, jo, ko; };
+static int strip_window(pcl_solver *s, int idim, int side, int width, StripWin &w) {
     if (idim < 0 || idim >= s->cfg.ndim) return fail(PCL_EINVAL, "bad idim");
-    const int N = idim == 0 ? s->I : s->J;
+    const int N = idim == 0 ? s->I : (idim == 1 ? s->J : s->K);
     if (width < 1 || width > N) return fail(PCL_EINVAL, "bad strip width");
-    ni = s->I; nj = s->J; io = 0; jo = 0;
-    if (idim == 0) { ni = width; io = side == 0 ? 0 : N - width; }
-    else { nj = width; jo = side == 0 ? 0 : N - width; }
+    w = StripWin{s->I, s->J, s->K, 0, 0, 0};
+    if (idim == 0) { w.ni = width; w.io = side == 0 ? 0 : N - width; }
+    else if (idim == 1) { w.nj = width; w.jo = side == 0 ? 0 : N - width; }
+    else { w.nk = width; w.ko = side == 0 ? 0 : N - width; }
     return PCL_OK;
 }
 
 int pcl_get_strip(pcl_solver *s, int idim, int side, int width, double *host) {
     if (!s || !host) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    int ni, nj, io, jo;
-    if (int rc = strip_window(s, idim, side, width, ni, nj, io, jo)) return rc;
+    StripWin w;
+    if (int rc = strip_window(s, idim, side, width, w)) return rc;
     const int nm = s->cfg.meqn;
-    dim3 grid((ni + 255) / 256, nj);
-    hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, cur(s), s->stage, nm, ni, nj, io, jo,
-                       s->pitch, s->plane);
+    dim3 grid((w.ni + 255) / 256, w.nj, w.nk);
+    hipLaunchKernelGGL(soa_to_aos, grid, dim3(256), 0, s->stream, cur(s), s->stage, nm, w.ni, w.nj, w.io, w.jo,
+                       s->pitch, s->plane, w.ko, s->pitch * s->J);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host, s->stage, (size_t)nm * ni * nj * sizeof(double), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(host, s->stage, (size_t)nm * w.ni * w.nj * w.nk * sizeof(double), hipMemcpyDeviceToHost,
                            s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PCL_OK;
@@ -899,14 +902,14 @@ int pcl_put_strip(pcl_solver *s, int idim, int side, int width, const double *ho
     if (s) s->ghosts_drop_all();          // exchange-ahead: whatever filled the ghost frames no longer holds
     if (!s || !host) return fail(PCL_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    int ni, nj, io, jo;
-    if (int rc = strip_window(s, idim, side, width, ni, nj, io, jo)) return rc;
+    StripWin w;
+    if (int rc = strip_window(s, idim, side, width, w)) return rc;
     const int nm = s->cfg.meqn;
-    HIP_TRY(hipMemcpyAsync(s->stage, host, (size_t)nm * ni * nj * sizeof(double), hipMemcpyHostToDevice,
+    HIP_TRY(hipMemcpyAsync(s->stage, host, (size_t)nm * w.ni * w.nj * w.nk * sizeof(double), hipMemcpyHostToDevice,
                            s->stream));
-    dim3 grid((ni + 255) / 256, nj);
-    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, cur(s), nm, ni, nj, io, jo,
-                       s->pitch, s->plane);
+    dim3 grid((w.ni + 255) / 256, w.nj, w.nk);
+    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, cur(s), nm, w.ni, w.nj, w.io, w.jo,
+                       s->pitch, s->plane, w.ko, s->pitch * s->J);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PCL_OK;
@@ -917,47 +920,52 @@ int pcl_put_aux_strip(pcl_solver *s, int idim, int side, int width, const double
     if (!s || !host) return fail(PCL_EINVAL, "null argument");
     if (s->cfg.maux <= 0 || !s->aux) return fail(PCL_ESTATE, "pcl_put_aux_strip: no aux array on the device");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    int ni, nj, io, jo;
-    if (int rc = strip_window(s, idim, side, width, ni, nj, io, jo)) return rc;
+    StripWin w;
+    if (int rc = strip_window(s, idim, side, width, w)) return rc;
     const int nm = s->cfg.maux;
-    if ((size_t)nm * ni * nj * sizeof(double) > s->stage_bytes) return fail(PCL_EINVAL, "pcl_put_aux_strip: strip exceeds the staging buffer");
-    HIP_TRY(hipMemcpyAsync(s->stage, host, (size_t)nm * ni * nj * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    dim3 grid((ni + 255) / 256, nj);
-    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, s->aux, nm, ni, nj, io, jo, s->pitch, s->plane);
+    const size_t bytes = (size_t)nm * w.ni * w.nj * w.nk * sizeof(double);
+    if (bytes > s->stage_bytes) return fail(PCL_EINVAL, "pcl_put_aux_strip: strip exceeds the staging buffer");
+    HIP_TRY(hipMemcpyAsync(s->stage, host, bytes, hipMemcpyHostToDevice, s->stream));
+    dim3 grid((w.ni + 255) / 256, w.nj, w.nk);
+    hipLaunchKernelGGL(aos_to_soa, grid, dim3(256), 0, s->stream, s->stage, s->aux, nm, w.ni, w.nj, w.io, w.jo, s->pitch, s->plane,
+                       w.ko, s->pitch * s->J);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PCL_OK;
 }
 
 __global__ void gather_cells_kernel(const double *q, const double *aux, const int *ij, double *out, int ncell,
-                                    int nq, int na, int mbc, int ndim, long pitch, long plane) {
+                                    int nq, int na, int mbc, int ndim, long pitch, long plane, long slab) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = nq + na;
     if (t >= ncell * per) return;
     const int c = t / per, m = t % per;
-    const long cell = (long)(ndim > 1 ? ij[2 * c + 1] + mbc : 0) * pitch + ij[2 * c] + mbc;
+    const int st = ndim > 2 ? 3 : 2;                  // index tuples: (i, j) pairs in 1-D / 2-D, (i, j, k) triples in 3-D
+    const long cell = (long)(ndim > 2 ? ij[st * c + 2] + mbc : 0) * slab + (long)(ndim > 1 ? ij[st * c + 1] + mbc : 0) * pitch +
+                      ij[st * c] + mbc;
     out[t] = m < nq ? q[m * plane + cell] : aux[(m - nq) * plane + cell];
 }
 
 int pcl_get_cells(pcl_solver *s, int ncell, const int *ij, double *q, double *aux) {
     if (!s || !ij || !q) return fail(PCL_EINVAL, "null argument");
-    if (s->cfg.ndim > 2) return fail(PCL_EINVAL, "pcl_get_cells is implemented for 1-D/2-D (the reference's gauges are (x,y) pairs)");
     if (ncell <= 0) return PCL_OK;
+    const int st = s->cfg.ndim > 2 ? 3 : 2;
     const int nq = s->cfg.meqn, na = (aux && s->aux) ? s->cfg.maux : 0, per = nq + na;
     if (aux && s->cfg.maux > 0 && !s->aux) return fail(PCL_EINVAL, "pcl_get_cells: aux requested but never uploaded");
     for (int c = 0; c < ncell; c++) {
-        const int i = ij[2 * c], j = s->cfg.ndim > 1 ? ij[2 * c + 1] : 0;
-        if (i < 0 || i >= s->cfg.n[0] || j < 0 || j >= (s->cfg.ndim > 1 ? s->cfg.n[1] : 1))
+        const int i = ij[st * c], j = s->cfg.ndim > 1 ? ij[st * c + 1] : 0, k = s->cfg.ndim > 2 ? ij[st * c + 2] : 0;
+        if (i < 0 || i >= s->cfg.n[0] || j < 0 || j >= (s->cfg.ndim > 1 ? s->cfg.n[1] : 1) ||
+            k < 0 || k >= (s->cfg.ndim > 2 ? s->cfg.n[2] : 1))
             return fail(PCL_EINVAL, "pcl_get_cells: cell index outside the interior");
     }
-    // staging layout: [ncell*per doubles of output][ncell*2 ints of indices]
-    const size_t out_bytes = (size_t)ncell * per * sizeof(double), idx_bytes = (size_t)ncell * 2 * sizeof(int);
+    // staging layout: [ncell*per doubles of output][ncell*st ints of indices]
+    const size_t out_bytes = (size_t)ncell * per * sizeof(double), idx_bytes = (size_t)ncell * st * sizeof(int);
     if (out_bytes + idx_bytes > s->stage_bytes) return fail(PCL_EINVAL, "pcl_get_cells: too many cells for the staging buffer");
     HIP_TRY(hipSetDevice(s->cfg.device));
     int *dij = reinterpret_cast<int *>(reinterpret_cast<char *>(s->stage) + out_bytes);
     HIP_TRY(hipMemcpyAsync(dij, ij, idx_bytes, hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(gather_cells_kernel, dim3((ncell * per + 255) / 256), dim3(256), 0, s->stream, cur(s),
-                       s->aux, dij, s->stage, ncell, nq, na, s->cfg.mbc, s->cfg.ndim, s->pitch, s->plane);
+                       s->aux, dij, s->stage, ncell, nq, na, s->cfg.mbc, s->cfg.ndim, s->pitch, s->plane, s->pitch * s->J);
     HIP_TRY(hipGetLastError());
     std::vector<double> tmp((size_t)ncell * per);
     HIP_TRY(hipMemcpyAsync(tmp.data(), s->stage, out_bytes, hipMemcpyDeviceToHost, s->stream));

@@ -543,7 +543,7 @@ class Solver(object):
         compute = self.compute_gauge_values or default_compute_gauge_values
         if self._resident and self._h is not None:
             n = len(gauges)
-            ij = np.zeros((n, 2), dtype=np.int32)
+            ij = np.zeros((n, 3 if state.grid.ndim > 2 else 2), dtype=np.int32)      # (i, j) pairs; (i, j, k) in 3-D
             for c, g in enumerate(gauges):
                 ij[c, :len(g)] = g
             qv = np.empty((n, state.meqn))
