@@ -155,29 +155,27 @@ def build3d(n, math, unsplit=False):
     return claw
 
 
-PMC_FILE = "r02_pmc_hbm.json"     # written by tools/profile_round.sh (falls back to the round-1 file)
+PMC_FILE = "r03_pmc_hbm.json"     # written by tools/profile_r03.sh + tools/pmc_summary.py
 
 
-def pmc_traffic(math, which, nx, ny, state="bubble"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<round>_pmc_hbm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
-    passes, same bench command).  PMC counters cannot be read from inside this process, so the
-    number is only reported for the configuration it was collected on (4096 x 4096), and
-    `traffic_source` says which committed profile (and which kernel build) it belongs to.
-    Returns (bytes or None, source string or None)."""
-    if (nx, ny) != (4096, 4096):
+def pmc_traffic(mode, needles, default_grid):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/<round>_pmc_hbm.json:
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, the same bench command).  PMC counters cannot be
+    read from inside this process, so the number is only reported for the configuration it was collected on
+    (`default_grid` says whether this run is that one), and `traffic_source` names the committed profile and the commit
+    of the kernel build it belongs to.  mode: key of the profile's "modes"; needles: substrings the kernel name must
+    contain.  Returns (bytes or None, source string or None)."""
+    if not default_grid:
         return None, None
-    for fn in (PMC_FILE, "r01_final_pmc_hbm.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", fn)) as f:
-                doc = json.load(f)
-            key = math if state == "bubble" else "%s_%s" % (math, state)
-            for name, v in doc["modes"][key].items():
-                if "sweep_kernel" in name and ("Euler5, %d," % (which + 1)) in name:
-                    return v["hbm_bytes_per_launch_corrected"], (
-                        "from committed profile profiles/%s (collected at commit %s)" % (fn, doc.get("commit", "round-1 HEAD")))
-        except Exception:
-            continue
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+            doc = json.load(f)
+        for name, v in doc["modes"][mode].items():
+            if all(n in name for n in needles):
+                return v["hbm_bytes_per_launch_corrected"], (
+                    "from committed profile profiles/%s (collected at commit %s)" % (PMC_FILE, doc.get("commit", "?")))
+    except Exception:
+        pass
     return None, None
 
 
@@ -463,19 +461,22 @@ def main():
         ns = "pcl::%s::" % args.math
         names = [ns + "sweep_kernel<Euler5, 1> (x pass)", ns + "sweep_kernel<Euler5, 2> (y pass)"]
         if args.unsplit:
-            names = [ns + "unsplit_x_kernel<Euler5> (x phase)", ns + "unsplit_y_kernel<Euler5> (y phase)"]
+            names = [ns + "unsplit_x_kernel<Euler5> (x phase)", ns + "unsplit_ym_kernel<Euler5> (y phase, marching)"]
         avg = [ms[k] / max(1, nl[k]) for k in range(2)]
         dom = int(np.argmax(avg))
         bytes_launch = BYTES_PER_CELL_SWEEP * float(args.nx) * float(args.ny)
+        if args.unsplit and args.ndim == 2:
+            # x phase: qold in, t1 out (80 B per cell); y phase: qold and t1 in, t1 out (120 B per cell)   
+            bytes_launch = [80.0, 120.0][dom] * float(args.nx) * float(args.ny)
         if args.ndim == 3:
             # per directional sweep: read q (4) + aux (2), write q (4) doubles per cell
             names = [ns + "sweep3_kernel<VcAcoustics3D, 1> (x sweep)", ns + "sweep3_kernel<VcAcoustics3D, 2|3> (y, z sweeps)"]
             bytes_launch = (4 + 2 + 4) * 8 * float(args.nx) ** 3
             if args.unsplit:
-                # per direction: slices3 (q + aux in, 14 scratch plane sets out) + combine3 (q + scratch in, q out);
-                # the timed launches are the two kernels of one direction together
-                names = [ns + "slices3 + combine3 <VcAcoustics3D, 1> (x direction)",
-                         ns + "slices3 + combine3 <VcAcoustics3D, 2|3> (y, z directions)"]
+                # per direction ONE marching kernel (classic3.hpp): qold + aux in, the accumulated state in and out
+                # (algorithmic: q in, aux in, q out = (4 + 2 + 4) doubles per cell, as for the dim-split sweep)
+                names = [ns + "march3p_kernel<VcAcoustics3D, 1> (x direction)",
+                         ns + "march3p_kernel<VcAcoustics3D, 2|3> (y, z directions)"]
         if args.solver == "sharpclaw":
             # x pass: read the stage (5), write dq (5); y pass: read the stage, dq and the RK operand, write the result
             names = [ns + "sharp_kernel<Euler5, 1> (x pass of one RK stage)",
@@ -495,8 +496,27 @@ def main():
                 per = [(4 + 16 + 4) * 8.0, (4 + 4 + 16 + 4) * 8.0]
             bytes_launch = per[dom] * float(args.nx) * float(args.ny)
         achieved = bytes_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
-        traffic, traffic_source = (pmc_traffic(args.math, dom, args.nx, args.ny, args.state) if headline
-                                   else (None, None))
+        # the committed PMC pass of the same command, for the default size of each line (tools/profile_r03.sh)
+        if args.ndim == 3:
+            pm = ("3d_unsplit", ["march3p_kernel", "VcAcoustics3D, %s," % ("1" if dom == 0 else "2")]) if args.unsplit else \
+                 ("3d_dimsplit", ["sweep3_kernel", "VcAcoustics3D, %s" % ("1" if dom == 0 else "2")])
+            dflt = size == 1 and args.math == "exact" and args.nx == (256 if args.unsplit else 512)
+        elif args.app == "sphere":
+            pm = ("sphere_sharpclaw", ["sharp_kernel", "ShallowSphere, %d" % (dom + 1)]) if args.solver == "sharpclaw" else \
+                 ("sphere_classic", ["unsplit_x_kernel" if dom == 0 else "unsplit_y_kernel", "ShallowSphere"])
+            dflt = size == 1 and args.math == "exact" and (nxg, nyg) == (2048, 1024)
+        elif args.solver == "sharpclaw":
+            pm = ("sharpclaw", ["sharp_kernel", "Euler5, %d" % (dom + 1)])
+            dflt = size == 1 and args.math == "exact" and (args.nx, args.ny) == (4096, 4096) and not args.dq_src
+        elif args.unsplit:
+            pm = ("unsplit", ["unsplit_x_kernel" if dom == 0 else "unsplit_ym_kernel", "Euler5"])
+            dflt = size == 1 and args.math == "exact" and (args.nx, args.ny) == (4096, 4096) and args.state == "bubble"
+        else:
+            key = {("exact", "bubble"): "exact", ("exact", "dense"): "exact_dense", ("fast", "dense"): "fast_dense"}.get(
+                (args.math, args.state))
+            pm = (key, ["sweep_kernel", "Euler5, %d," % (dom + 1)])
+            dflt = size == 1 and key is not None and (args.nx, args.ny) == (4096, 4096)
+        traffic, traffic_source = pmc_traffic(pm[0], pm[1], dflt)
         if scaling == "strong":
             grid_note = ("GLOBAL grid %dx%d fixed (strong scaling), %dx%d blocks, %dx%d cells on rank 0"
                          % (nxg, nyg, dims[0], dims[1], args.nx, args.ny))

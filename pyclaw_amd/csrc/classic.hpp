@@ -427,13 +427,20 @@ template <int IXY> struct TileShape {
     static constexpr int NSTRIP = IXY == 1 ? 4 : 1;                 // strips along the sweep per tile
     static constexpr int ALONG = NSTRIP * STRIP + 2 * HALO;         // cells loaded along the sweep
     static constexpr int ACROSS = IXY == 1 ? 4 : 16;                // cells across
-    static constexpr int PLANE = ACROSS * ALONG;
+#ifndef PCL_YTILE_PAD       /* 1: the round-1 layout (17th padding double per row) -- A/B builds for the bank-conflict counters */
+#define PCL_YTILE_PAD 0
+#endif
+    static constexpr int PLANE = (IXY == 2 && PCL_YTILE_PAD) ? (ACROSS + 1) * ALONG : ACROSS * ALONG;
     static constexpr int UNITS = NSTRIP * ACROSS / 4;               // strips per wavefront
     __device__ static __forceinline__ int at(int m, int al, int ac) {
         // y pass: rows of 16 doubles, the column XOR-swizzled with bits 1..4 of the row instead of a 17th padding
         // double: a wavefront reading one column of 64 rows still hits 32 different 8-byte banks per half, and the five
         // Euler planes take 40960 B instead of 43520 -- FOUR workgroups per CU (160 KB) instead of three
+#if PCL_YTILE_PAD
+        return IXY == 1 ? (m * ACROSS + ac) * ALONG + al : m * PLANE + al * (ACROSS + 1) + ac;
+#else
         return IXY == 1 ? (m * ACROSS + ac) * ALONG + al : (m * ALONG + al) * ACROSS + (ac ^ ((al >> 1) & (ACROSS - 1)));
+#endif
     }
 };
 constexpr int LINE = 16;  // doubles per 128-byte line

@@ -1,0 +1,81 @@
+#!/bin/bash
+# Round-3 profile artefacts (run through gpurun; copy gpurun_out/prof_<tag>/summary/* into profiles/ afterwards).
+#   1. rocprofv3 --kernel-trace --stats of one bench command per kernel family, the bench JSON of the SAME run next to it;
+#   2. in SEPARATE passes --pmc FETCH_SIZE / --pmc WRITE_SIZE (MI355X_MICROARCH.md: KB units, FETCH_SIZE x2 on gfx950) of
+#      the same commands -> <tag>_pmc_hbm.json via tools/pmc_summary.py (bench.py reads roofline.traffic from it);
+#   3. SQ issue counters of the dense state, and SQ_LDS_BANK_CONFLICT of the y pass with the swizzled tile (the build)
+#      and with the padded round-1 tile (build/libs/libpyclaw_amd_ypad.so, -DPCL_YTILE_PAD=1).
+# Usage: tools/profile_r03.sh <tag> <commit>
+set -e
+TAG=${1:-r03}
+COMMIT=${2:-unknown}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT/summary
+cd /tmp && export TMPDIR=/tmp
+B="--no-cpu-baseline --no-states"
+declare -A CMD
+CMD[exact]="$R/bench.py $B --math exact"
+CMD[exact_dense]="$R/bench.py $B --math exact --state dense"
+CMD[fast_dense]="$R/bench.py $B --math fast --state dense"
+CMD[unsplit]="$R/bench.py $B --unsplit"
+CMD[sharpclaw]="$R/bench.py $B --solver sharpclaw"
+CMD[3d_dimsplit]="$R/bench.py --ndim 3 --nx 512"
+CMD[3d_unsplit]="$R/bench.py --ndim 3 --unsplit --nx 256"
+CMD[sphere_classic]="$R/bench.py --app sphere"
+CMD[sphere_sharpclaw]="$R/bench.py --app sphere --solver sharpclaw"
+ORDER="exact exact_dense fast_dense unsplit sharpclaw 3d_dimsplit 3d_unsplit sphere_classic sphere_sharpclaw"
+for name in $ORDER; do
+  steps=20; [ "$name" = sharpclaw ] && steps=4; [ "$name" = 3d_dimsplit ] && steps=6; [ "$name" = 3d_unsplit ] && steps=6
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 ${CMD[$name]} --steps $steps --warmup 3 \
+      > $OUT/summary/${TAG}_bench_$name.json 2> $OUT/stats_$name.err
+  cp $(find $OUT/stats_$name -name "*kernel_stats.csv" | head -1) $OUT/summary/${TAG}_kernel_stats_$name.csv
+  echo "stats $name done"
+done
+for name in $ORDER; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${name}_$C -- python3 ${CMD[$name]} --steps 2 --warmup 1 > $OUT/pmc_${name}_$C.log 2>&1
+  done
+  echo "pmc $name done"
+done
+python3 $R/tools/pmc_summary.py $OUT > $OUT/pmc_modes.json
+SQA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
+SQB="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/sq_a -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_a.log 2>&1
+rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/sq_b -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_b.log 2>&1
+rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/sq_fast_a -- python3 ${CMD[fast_dense]} --steps 3 --warmup 1 > $OUT/sq_fast_a.log 2>&1
+export PCL_LIB_OVERRIDE=$R/build/libs/libpyclaw_amd_ypad.so
+rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/sq_b_ypad -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_b_ypad.log 2>&1
+unset PCL_LIB_OVERRIDE
+echo "sq done"
+python3 - $OUT $TAG $COMMIT <<'PY'
+import csv, glob, json, sys, collections
+out, tag, commit = sys.argv[1], sys.argv[2], sys.argv[3]
+modes = json.load(open(out + "/pmc_modes.json"))
+res = {"commit": commit,
+       "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py <the command of the mode> --steps 2 --warmup 1",
+       "correction": "MI355X_MICROARCH.md HBM section: counters are in KB; on gfx950 FETCH_SIZE reads 1/2 of streamed bytes -> x2; WRITE_SIZE exact",
+       "modes": modes}
+json.dump(res, open("%s/summary/%s_pmc_hbm.json" % (out, tag), "w"), indent=1)
+with open("%s/summary/%s_pmc_sq.txt" % (out, tag), "w") as fo:
+    fo.write("rocprofv3 --pmc <SQ counters> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-states "
+             "--state dense   (commit %s)\n  sq_a / sq_b: --math exact, two passes of 8 counters;  sq_fast_a: --math fast;\n"
+             "  sq_b_ypad: the sq_b counters with build/libs/libpyclaw_amd_ypad.so (-DPCL_YTILE_PAD=1: the y-pass tile padded to 17 "
+             "doubles per row instead of XOR-swizzled) -- the before / after pair for SQ_LDS_BANK_CONFLICT\n" % commit)
+    for sub in ("sq_a", "sq_b", "sq_fast_a", "sq_b_ypad"):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+        for f in glob.glob(out + "/%s/**/*counter_collection.csv" % sub, recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"]
+                if "sweep_kernel" not in k: continue
+                k = k[:80]
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                n[(k, r["Counter_Name"])] += 1
+        fo.write("== %s\n" % sub)
+        for k in acc:
+            fo.write(k + "\n")
+            for c, v in sorted(acc[k].items()):
+                fo.write("   %-24s %.5g per launch (%d launches)\n" % (c, v / n[(k, c)], n[(k, c)]))
+print(open("%s/summary/%s_pmc_sq.txt" % (out, tag)).read()[:6000])
+PY
+ls $OUT/summary
