@@ -538,6 +538,7 @@ def main():
                                 else "strict (exact + IEEE quotients for underflow-range numerators)" if args.math == "strict"
                                 else "fast (FMA contraction, reciprocal-multiply division; rtol 1e-12 vs reference)"),
                        "halo_transport": getattr(claw.solver, "halo_transport", "none (one block)"),
+                       "exchange_ahead": bool(getattr(claw.solver, "exchange_ahead", False)),
                        "launches_timed": {names[0]: int(nl[0]), names[1]: int(nl[1])},
                        "steps_incl_rejected": int(attempted), "result_finite": finite},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,

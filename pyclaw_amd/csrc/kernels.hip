@@ -254,15 +254,18 @@ template <class RP, int UX, int UY> int launch_unsplit_u(const SweepLaunch &l, c
         const int ntj = (a.my + STRIP - 1) / STRIP;
         static const int ymarch = [] { const char *e = getenv("PCL_TUNE_YMARCH"); return e ? atoi(e) : 1; }();
         if constexpr (RP::NAUX == 0 && UY == 16) {
-            if (ymarch && a.mcapa <= 0 && (a.src_id == 0 || std::is_same<RP, Euler5>::value)) {
-                // marching y phase (classic.hpp: unsplit_ym_kernel): segments of `seg` lines of 16 columns; enough
-                // workgroups for ~4 rounds over the 256 CUs, warm-up step of a segment <= 1/8 of its work
-                const int nlines = (a.mx + 15) / 16;
-                int nseg = (1024 + ntj - 1) / ntj;
-                if (nseg > (nlines + 7) / 8) nseg = (nlines + 7) / 8;
-                if (nseg < 1) nseg = 1;
-                const int seg = (nlines + nseg - 1) / nseg;
-                nseg = (nlines + seg - 1) / seg;
+            // marching y phase (classic.hpp: unsplit_ym_kernel): segments of `seg` lines of 16 columns; enough
+            // workgroups for ~4 rounds over the 256 CUs, warm-up step of a segment <= 1/8 of its work
+            const int nlines = (a.mx + 15) / 16;
+            int nseg = (1024 + ntj - 1) / ntj;
+            if (nseg > (nlines + 7) / 8) nseg = (nlines + 7) / 8;
+            if (nseg < 1) nseg = 1;
+            const int seg = (nlines + nseg - 1) / nseg;
+            nseg = (nlines + seg - 1) / seg;
+            // a small grid cannot give every CU two marching workgroups (1024^2: 18 bands x 8 segments = 144; 2048^2: 560): the tile
+            // kernel's many independent workgroups are the better shape there (C2, acoustics 1024^2: 103 vs 131 us per step; 2048^2: 240 vs 249; 4096^2: 731 vs 702, same box)
+            const bool big = (long)ntj * nseg >= 1024 || ymarch == 8 || ymarch == 16;
+            if (ymarch && big && a.mcapa <= 0 && (a.src_id == 0 || std::is_same<RP, Euler5>::value)) {
                 // wavefronts per workgroup: 8 (two slices each per step, 256 VGPRs: no spills) for the register-heavy
                 // Euler core, 16 for the small systems; PCL_TUNE_YMARCH=16 / 8 forces one
                 constexpr bool heavy = RP::MEQN >= 5;
