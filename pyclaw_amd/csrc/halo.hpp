@@ -29,17 +29,20 @@ struct HaloRegion { int i0, j0, ni, nj; };
 
 // strip to SEND towards direction d (interior cells next to that edge) when send=true,
 // ghost strip to FILL from direction d when send=false
-__host__ __device__ inline HaloRegion halo_region(int d, bool send, int I, int J, int g) {
-    const int mx = I - 2 * g, my = J - 2 * g;
+// gy: ghost width of the second index (default = g; 0 for a 1-D grid, whose single row has no ghost rows: only the
+// W and E strips exist then)
+__host__ __device__ inline HaloRegion halo_region(int d, bool send, int I, int J, int g, int gy = -1) {
+    if (gy < 0) gy = g;
+    const int mx = I - 2 * g, my = J - 2 * gy;
     int xs, xn, ys, yn;  // x start/len, y start/len
     const bool west = (d == W || d == SW || d == NW), east = (d == E || d == SE || d == NE);
     const bool south = (d == S || d == SW || d == SE), north = (d == N || d == NW || d == NE);
     if (west) { xs = send ? g : 0; xn = g; }
     else if (east) { xs = send ? I - 2 * g : I - g; xn = g; }
     else { xs = g; xn = mx; }
-    if (south) { ys = send ? g : 0; yn = g; }
-    else if (north) { ys = send ? J - 2 * g : J - g; yn = g; }
-    else { ys = g; yn = my; }
+    if (south) { ys = send ? gy : 0; yn = gy; }
+    else if (north) { ys = send ? J - 2 * gy : J - gy; yn = gy; }
+    else { ys = gy; yn = my; }
     return HaloRegion{xs, ys, xn, yn};
 }
 
@@ -48,6 +51,7 @@ struct HaloPlan {
     long off[8];  // offset (doubles, per component count 1) of each direction's buffer
     long cnt[8];  // doubles per component in each direction's strip (cells x elem)
     int I, J, g;  // the decomposed index plane (with ghosts) and the ghost width
+    int gy;       // ghost width of the plane's second index (= g; 0 for 1-D grids)
     // 2-D blocks: the plane is (i, j), one cell per element: elem = 1, pi = 1, pj = pitch.
     // 3-D blocks decomposed over (y, z): the plane is (j, k) and every element is a whole x-row of the
     // array (elem = cells per row incl. ghosts, contiguous): pi = pitch, pj = pitch * J3.
@@ -59,7 +63,7 @@ __global__ void halo_pack(const double *q, double *buf, HaloPlan p, int nm, long
                           bool unpack) {
     const int d = blockIdx.y;
     if (p.nbr[d] < 0) return;
-    const HaloRegion r = halo_region(d, !unpack, p.I, p.J, p.g);
+    const HaloRegion r = halo_region(d, !unpack, p.I, p.J, p.g, p.gy);
     const long ncell = (long)r.ni * r.nj * p.elem;
     (void)pitch;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell * nm;
@@ -107,17 +111,17 @@ public:
     }
 
     int init(int nranks, int rank, const char uid[128], const int nbr[8], int I, int J, int g,
-             int nmax, hipStream_t stream, std::string &err, int elem = 1, long pi = 1, long pj = 0) {
+             int nmax, hipStream_t stream, std::string &err, int elem = 1, long pi = 1, long pj = 0, int gy = -1) {
         if (load(err)) return -1;
         destroy();
         stream_ = stream;
-        plan_.I = I; plan_.J = J; plan_.g = g;
+        plan_.I = I; plan_.J = J; plan_.g = g; plan_.gy = gy < 0 ? g : gy;
         plan_.elem = elem; plan_.pi = pi; plan_.pj = pj;
         long off = 0;
         for (int d = 0; d < 8; d++) {
             if (nbr[d] >= nranks) { err = "neighbour rank out of range"; return -1; }
             plan_.nbr[d] = nbr[d];
-            const HaloRegion r = halo_region(d, true, I, J, g);
+            const HaloRegion r = halo_region(d, true, I, J, g, plan_.gy);
             plan_.cnt[d] = (long)r.ni * r.nj * elem;
             plan_.off[d] = off;
             off += plan_.cnt[d];
@@ -147,17 +151,17 @@ public:
                               const int *nbr, int nm);
     typedef int (*ReduceFn)(void *user, double *value);
     int init_host(int nranks, int rank, const int nbr[8], int I, int J, int g, int nmax, hipStream_t stream,
-                  ExchangeFn xfn, ReduceFn rfn, void *user, std::string &err, int elem = 1, long pi = 1, long pj = 0) {
+                  ExchangeFn xfn, ReduceFn rfn, void *user, std::string &err, int elem = 1, long pi = 1, long pj = 0, int gy = -1) {
         destroy();
         (void)rank;
         stream_ = stream;
-        plan_.I = I; plan_.J = J; plan_.g = g;
+        plan_.I = I; plan_.J = J; plan_.g = g; plan_.gy = gy < 0 ? g : gy;
         plan_.elem = elem; plan_.pi = pi; plan_.pj = pj;
         long off = 0;
         for (int d = 0; d < 8; d++) {
             if (nbr[d] >= nranks) { err = "neighbour rank out of range"; return -1; }
             plan_.nbr[d] = nbr[d];
-            const HaloRegion r = halo_region(d, true, I, J, g);
+            const HaloRegion r = halo_region(d, true, I, J, g, plan_.gy);
             plan_.cnt[d] = (long)r.ni * r.nj * elem;
             plan_.off[d] = off;
             off += plan_.cnt[d];

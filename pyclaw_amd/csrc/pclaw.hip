@@ -1854,7 +1854,6 @@ int pcl_comm_check(int nranks, int rank, const int neighbors[8]) {
 
 int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], const int neighbors[8]) {
     if (!s || !uid || !neighbors) return fail(PCL_EINVAL, "null argument");
-    if (s->cfg.ndim < 2) return fail(PCL_EINVAL, "halo exchange is implemented for 2-D blocks and 3-D blocks decomposed over (y, z)");
     // argument validation BEFORE anything reaches RCCL (whose own diagnostics for these mistakes is a bare
     // "invalid usage" from ncclCommInitRank)
     if (int rc = pcl_comm_check(nranks, rank, neighbors)) return rc;
@@ -1869,7 +1868,7 @@ int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], cons
                         ? s->halo.init(nranks, rank, uid, neighbors, s->J, s->K, s->cfg.mbc, nmax, s->stream, err, s->I,
                                        s->pitch, s->pitch * s->J)
                         : s->halo.init(nranks, rank, uid, neighbors, s->I, s->J, s->cfg.mbc, nmax, s->stream, err, 1, 1,
-                                       s->pitch);
+                                       s->pitch, s->cfg.ndim == 1 ? 0 : -1);     // 1-D: a single row, W / E strips only
     if (rc3) return fail(PCL_ECOMM, err);
     if (!s->hstream) {
         HIP_TRY(create_halo_stream(&s->hstream));
@@ -1884,7 +1883,6 @@ int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], cons
 int pcl_comm_init_host(pcl_solver *s, int nranks, int rank, const int neighbors[8], pcl_host_exchange_fn xfn,
                        pcl_host_reduce_fn rfn, void *user) {
     if (!s || !neighbors || !xfn || !rfn) return fail(PCL_EINVAL, "null argument");
-    if (s->cfg.ndim < 2) return fail(PCL_EINVAL, "halo exchange is implemented for 2-D blocks and 3-D blocks decomposed over (y, z)");
     if (int rc = pcl_comm_check(nranks, rank, neighbors)) return rc;
     HIP_TRY(hipSetDevice(s->cfg.device));
     std::string err;
@@ -1893,7 +1891,7 @@ int pcl_comm_init_host(pcl_solver *s, int nranks, int rank, const int neighbors[
                         ? s->halo.init_host(nranks, rank, neighbors, s->J, s->K, s->cfg.mbc, nmax, s->stream, xfn, rfn, user,
                                             err, s->I, s->pitch, s->pitch * s->J)
                         : s->halo.init_host(nranks, rank, neighbors, s->I, s->J, s->cfg.mbc, nmax, s->stream, xfn, rfn, user,
-                                            err, 1, 1, s->pitch);
+                                            err, 1, 1, s->pitch, s->cfg.ndim == 1 ? 0 : -1);
     if (rc3) return fail(PCL_ECOMM, err);
     if (!s->hstream) {
         HIP_TRY(create_halo_stream(&s->hstream));

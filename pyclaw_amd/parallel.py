@@ -440,9 +440,10 @@ def decompose(grid):
     existing = getattr(grid, "_decomp", None)
     if existing is not None:
         return existing
-    if len(grid.n) == 1:
-        # a 1-D grid is a single row of cells: every rank keeps the whole row (replicas); the device halo exchange
-        # (pcl_comm_init) serves 2-D blocks and 3-D blocks cut in (y, z)
+    if len(grid.n) == 1 and (os.environ.get("PCL_DECOMPOSE_1D", "1") == "0" or grid.n[0] < 8 * world_size()):
+        # PetClaw cuts 1-D grids too (petclaw/state.py:199-234), and so does this layer since round 3 (W / E strips only).
+        # Replicas -- every rank keeps the whole row -- remain for PCL_DECOMPOSE_1D=0 and for rows too short to give
+        # every rank a few cells beyond its ghost width.
         return None
     dec = Decomposition(grid.n, world_size(), rank())
     for k, dim in enumerate(grid.dimensions):

@@ -43,6 +43,10 @@ def run_case(case):
         aux = co.sphere_setaux(3, mx, my, -3.0, -1.0, 4.0 / mx, 2.0 / my)
         q0 = co.sphere_qinit(3, mx, my, -3.0, -1.0, 4.0 / mx, 2.0 / my)[:, 3:-3, 3:-3]
         return S.shallow_sphere(pyclaw, mx, my, tfinal=0.5, nout=1, aux_full=aux, q0=q0, solver_type='sharpclaw')
+    if case == "advection1d":               # 1-D grids are cut too (petclaw/state.py:199-234): W / E strips, periodic wrap
+        return problems.advection1D(pyclaw, mx=1000, tfinal=0.3, nout=2)
+    if case == "acoustics1d_sharp":         # SharpClaw in 1-D: every Runge-Kutta stage exchanges its 3-cell halo
+        return problems.acoustics1D(pyclaw, mx=300, solver_type='sharpclaw')[1]
     if case == "shockbubble_ds":
         claw = problems.shockbubble(pyclaw, mx=160, my=40, tfinal=0.03, device_callbacks=True)
     elif case == "shockbubble_unsplit":
@@ -86,6 +90,14 @@ def oracle_case(case):
     if case == "sphere_sharpclaw":
         p = D.shallow_sphere_problem(co, mx=48, my=24, solver_type='sharpclaw')
         D.run(p, co, 0.5, 1)
+        return p.q, p
+    if case == "advection1d":
+        p = D.advection1d_problem(mx=1000)
+        D.run(p, co, 0.3, 2)
+        return p.q, p
+    if case == "acoustics1d_sharp":
+        p = D.acoustics1d_problem(mx=300, solver_type='sharpclaw', cfl_max=2.5, cfl_desired=2.45)
+        D.run(p, co, 1.0, 5)
         return p.q, p
     if case.startswith("shockbubble"):
         p = D.shockbubble_problem(mx=160, my=40, dim_split=not case.endswith("_unsplit"))

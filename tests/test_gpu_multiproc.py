@@ -59,7 +59,8 @@ def launch(case, nranks, overlap=None):
                                          ("sphere_classic", 2), ("sphere_classic", 4),
                                          ("sphere_sharpclaw", 2), ("sphere_sharpclaw", 4),
                                          ("acoustics_odd", 5), ("acoustics_odd", 3), ("acoustics_odd", 4),
-                                         ("acoustics_ds_mbc3", 2), ("acoustics_ds_mbc3", 4)])
+                                         ("acoustics_ds_mbc3", 2), ("acoustics_ds_mbc3", 4),
+                                         ("advection1d", 2), ("advection1d", 3), ("acoustics1d_sharp", 4)])
 def test_decomposed_device_run_equals_serial(case, nranks):
     launch(case, nranks)
 

@@ -199,3 +199,22 @@ def test_package_control_plane_is_torch_free():
             "assert 'torch' not in sys.modules, 'torch imported'; print('ok')")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT if 'ROOT' in globals() else None)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_1d_grids_are_decomposed_like_petclaw():
+    """petclaw/state.py:199-234 cuts 1-D grids too: ranges (remainder first, PETSc's rule) and W / E neighbours with the
+    periodic wrap; no S / N / corner neighbours"""
+    from pyclaw_amd import parallel
+    for size in (2, 3, 5):
+        got = []
+        for r in range(size):
+            dec = parallel.Decomposition([1000], size, r)
+            assert dec.dims == [size] and dec.coords == [r]
+            got.append(dec.ranges[0])
+            nb = dec.neighbors([True])
+            assert nb[2:] == [-1] * 6
+            assert nb[0] == (r - 1) % size and nb[1] == (r + 1) % size
+            nb = dec.neighbors([False])
+            assert nb[0] == (r - 1 if r > 0 else -1) and nb[1] == (r + 1 if r < size - 1 else -1)
+        assert got[0][0] == 0 and got[-1][1] == 1000 and all(got[k][1] == got[k + 1][0] for k in range(size - 1))
+        assert max(b - a for a, b in got) - min(b - a for a, b in got) <= 1
