@@ -774,13 +774,29 @@ __global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3A
     constexpr int IE = DIR % 3 + 1, IF = (DIR + 1) % 3 + 1;      // components of the y-like / z-like velocity
     // xbuf[w][side][o][A.p | B.p | A.v | B.v][lane]: side 0 = for the slice w+1, 1 = for the slice w-1; o = M offset + 1
     __shared__ double xbuf[NW][2][3][4][WAVE];
+    // y and z sweeps: the lanes of a wavefront are `pitch` doubles apart in memory, 64 lines per load / store
+    // instruction, and with ~18 of them per step the texture addresser -- not the VALU -- set the pace (x direction
+    // 1.14 ms, y / z 1.49 ms at 256^3).  Their wave axis is i, the contiguous one: the workgroup loads and stores
+    // 64-row x NW-column tiles cooperatively (8 doubles = 64 B per row segment, 8 segments per instruction instead of
+    // 64 lines) and transposes them through LDS.  STAGED tiles: the next plane's cell values (tq1), the accumulated
+    // state two planes ahead (tq2: what that plane's accumulator starts from), the aux face two planes ahead (ta,
+    // NW + 2 columns), and -- in xbuf's memory, free between two exchanges -- the finished plane on its way out.
+    constexpr bool STAGED = DIR != 1;
+    constexpr int TP = NW + 1, TAP = NW + 3;
+    __shared__ double tq1[STAGED ? MEQN : 1][STAGED ? WAVE : 1][STAGED ? TP : 1];
+    __shared__ double tq2[STAGED ? MEQN : 1][STAGED ? WAVE : 1][STAGED ? TP : 1];
+    __shared__ double tau[STAGED ? NAUX : 1][STAGED ? WAVE : 1][STAGED ? TAP : 1];
+    static_assert(!STAGED || MEQN * WAVE * TP <= NW * 2 * 3 * 4 * WAVE, "the outgoing tile lives in xbuf");
+    double(*tout)[WAVE][TP] = reinterpret_cast<double(*)[WAVE][TP]>(&xbuf[0][0][0][0][0]);
+    constexpr int NT = NW * WAVE;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int bid = DIR == 1 ? (int)blockIdx.x : xcd_logical_block(a.xcd);
     const int tw = bid % g.ntiles_w, ta = (bid / g.ntiles_w) % g.ntiles_al, ts = bid / (g.ntiles_w * g.ntiles_al);
     const int a0 = a.mbc - HALO + ta * STRIP;
     const int ca = a0 + lane;
     const int cc = ca < a.n_al ? ca : a.n_al - 1;
-    const int cw = a.mbc - 1 + tw * (NW - 2) + w;
+    const int cw0 = a.mbc - 1 + tw * (NW - 2);
+    const int cw = cw0 + w;
     const bool w_live = cw <= a.mbc + g.m_w;                           // wave-uniform
     const int cwc = cw < g.n_w ? cw : g.n_w - 1;
     const bool target_w = w >= 1 && w <= NW - 2 && cw >= a.mbc && cw < a.mbc + g.m_w;
@@ -790,25 +806,85 @@ __global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3A
     const int tm1 = tm0 + g.seg < a.mbc + g.m_m ? tm0 + g.seg : a.mbc + g.m_m;
     const long base = (long)cc * a.s_al + (long)cwc * g.s_w;
     const int wl = w > 0 ? w - 1 : w, wr = w < NW - 1 ? w + 1 : w;
+    // this thread's cell of the cooperative tiles: row tr along the sweep, column tc along the wave axis
+    const int tc = threadIdx.x % NW, tr = threadIdx.x / NW;
+    const int trow = a0 + tr < a.n_al ? a0 + tr : a.n_al - 1;
+    const int tcol = cw0 + tc < g.n_w ? cw0 + tc : g.n_w - 1;
+    const long tbase = (long)trow * a.s_al + (long)tcol * g.s_w;
+    const bool t_owned = (a0 + tr >= a.mbc) && (a0 + tr < a.mbc + a.m_al) && tr >= HALO && tr < WAVE - HALO && tc >= 1 &&
+                         tc <= NW - 2 && cw0 + tc >= a.mbc && cw0 + tc < a.mbc + g.m_w;
     double cflmax = 0.0;
-    double accP[MEQN], acc0[MEQN], accM[MEQN];
+    double accP[MEQN], acc0[MEQN], accM[MEQN], accN[MEQN];
 #pragma unroll
-    for (int m = 0; m < MEQN; m++) { accP[m] = 0.0; acc0[m] = 0.0; accM[m] = 0.0; }
+    for (int m = 0; m < MEQN; m++) { accP[m] = 0.0; acc0[m] = 0.0; accM[m] = 0.0; accN[m] = 0.0; }
 
     // The 3 x 3 aux block and the cell itself travel with the march: per step only the face ahead (three cells of the
-    // wave axis at plane pm+2) and the next cell are loaded -- 6 + 4 loads instead of 18 + 2 + 4, issued BEFORE the
-    // exchange so that they are in flight through it.  (For the y and z sweeps the lanes of a load are `pitch` apart:
-    // 64 lines per instruction; with 28 such loads per step the texture addresser, not the VALU, set the pace.)
+    // wave axis at plane pm+2) and the next cell are needed -- 6 + 4 values instead of 18 + 2 + 4.
     double blkR[3][3][NAUX], qc[MEQN];
     {
         const long g0 = base + (long)(tm0 - 1) * g.s_m;
         load_blk<RP, DIR>(a, t, g0, E_OUTER ? tm0 - 1 : cwc, E_OUTER ? cwc : tm0 - 1, blkR);
 #pragma unroll
         for (int m = 0; m < MEQN; m++) qc[m] = a.qin[m * a.plane + g0];
+        if (STAGED && target_w) {      // the first target plane's starting value (later ones come through tq2)
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) accN[m] = g.qsrc[m * a.plane + g0 + g.s_m];
+        }
     }
     const long sw_lo = cwc > 0 ? -g.s_w : 0, sw_hi = cwc + 1 < g.n_w ? g.s_w : 0;      // wave-axis neighbours, clamped like load_blk
     for (int pm = tm0 - 1; pm <= tm1; pm++) {
         const long gc = base + (long)pm * g.s_m;
+        // ---- loads for the NEXT step, in flight through this step's arithmetic
+        double qn[MEQN], face[3][NAUX];
+        double gq[MEQN], gs[MEQN], ga[2][NAUX];
+        if constexpr (STAGED) {
+            const long tg = tbase + (long)pm * g.s_m;
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) gq[m] = a.qin[m * a.plane + tg + g.s_m];
+            if (pm < tm1) {      // uniform
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) gs[m] = g.qsrc[m * a.plane + tg + 2 * g.s_m];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const int id = threadIdx.x + k2 * NT;
+                    const int ac_ = id % (NW + 2), ar_ = id / (NW + 2);
+                    int col = cw0 - 1 + ac_;
+                    col = col < 0 ? 0 : (col < g.n_w ? col : g.n_w - 1);
+                    const int row = a0 + ar_ < a.n_al ? a0 + ar_ : a.n_al - 1;
+#pragma unroll
+                    for (int k = 0; k < NAUX; k++)
+                        ga[k2][k] = ar_ < WAVE ? a.aux[aux_idx<RP, DIR>(k) * a.plane + (long)row * a.s_al + (long)col * g.s_w + (long)(pm + 2) * g.s_m] : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) gs[m] = 0.0;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                    for (int k = 0; k < NAUX; k++) ga[k2][k] = 0.0;
+            }
+            if (target_w) {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) accP[m] = accN[m];      // plane pm+1 starts from the accumulated state
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) qn[m] = a.qin[m * a.plane + gc + g.s_m];
+            if (pm < tm1) {      // uniform
+#pragma unroll
+                for (int k = 0; k < NAUX; k++) {
+                    const long at = aux_idx<RP, DIR>(k) * a.plane + gc + 2 * g.s_m;
+                    face[0][k] = a.aux[at + sw_lo]; face[1][k] = a.aux[at]; face[2][k] = a.aux[at + sw_hi];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NAUX; k++) { face[0][k] = blkR[1][1][k]; face[1][k] = blkR[1][1][k]; face[2][k] = blkR[1][1][k]; }
+            }
+            if (target_w) {      // wave-uniform; x direction: the accumulator starts from qold = the next cell itself
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) accP[m] = qn[m];
+            }
+        }
         P2 qadd{0.0, 0.0}, df{0.0, 0.0}, G[2][3], H[2][3];
         if (w_live) {
             double auxv[NAUX];
@@ -820,30 +896,6 @@ __global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3A
             for (int k = 0; k < 2; k++)
 #pragma unroll
                 for (int j = 0; j < 3; j++) { G[k][j].p = 0.0; G[k][j].v = 0.0; H[k][j].p = 0.0; H[k][j].v = 0.0; }
-        }
-        // the next plane: its cell (x direction: also what the accumulator of that plane starts from) and the aux face
-        // two planes ahead
-        double qn[MEQN], face[3][NAUX];
-#pragma unroll
-        for (int m = 0; m < MEQN; m++) qn[m] = a.qin[m * a.plane + gc + g.s_m];
-        if (pm < tm1) {      // uniform
-#pragma unroll
-            for (int k = 0; k < NAUX; k++) {
-                const long at = aux_idx<RP, DIR>(k) * a.plane + gc + 2 * g.s_m;
-                face[0][k] = a.aux[at + sw_lo]; face[1][k] = a.aux[at]; face[2][k] = a.aux[at + sw_hi];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NAUX; k++) { face[0][k] = blkR[1][1][k]; face[1][k] = blkR[1][1][k]; face[2][k] = blkR[1][1][k]; }
-        }
-        if (target_w) {      // wave-uniform
-            if (DIR == 1) {
-#pragma unroll
-                for (int m = 0; m < MEQN; m++) accP[m] = qn[m];
-            } else {
-#pragma unroll
-                for (int m = 0; m < MEQN; m++) accP[m] = g.qsrc[m * a.plane + gc + g.s_m];
-            }
         }
 #pragma unroll
         for (int side = 0; side < 2; side++)
@@ -882,9 +934,44 @@ __global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3A
             acc[0] = vp; acc[IE] = ve; acc[IF] = vf;
         }
         __syncthreads();
-        if (owned && pm - 1 >= tm0 && pm - 1 < tm1) {
+        const bool plane_out = pm - 1 >= tm0 && pm - 1 < tm1;           // the plane behind is complete (uniform)
+        if constexpr (STAGED) {
+            // transpose: the loaded tiles in, the finished plane out (tout shares xbuf's memory: every wavefront is past
+            // the exchange)
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) g.qacc[m * a.plane + gc - g.s_m] = accM[m];
+            for (int m = 0; m < MEQN; m++) {
+                tq1[m][tr][tc] = gq[m];
+                tq2[m][tr][tc] = gs[m];
+                tout[m][lane][w] = accM[m];
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+                const int id = threadIdx.x + k2 * NT;
+                const int ac_ = id % (NW + 2), ar_ = id / (NW + 2);
+                if (ar_ < WAVE) {
+#pragma unroll
+                    for (int k = 0; k < NAUX; k++) tau[k][ar_][ac_] = ga[k2][k];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) { qn[m] = tq1[m][lane][w]; accN[m] = tq2[m][lane][w]; }
+#pragma unroll
+            for (int k = 0; k < NAUX; k++) {
+                if (pm < tm1) { face[0][k] = tau[k][lane][w]; face[1][k] = tau[k][lane][w + 1]; face[2][k] = tau[k][lane][w + 2]; }
+                else { face[0][k] = blkR[1][1][k]; face[1][k] = blkR[1][1][k]; face[2][k] = blkR[1][1][k]; }
+            }
+            if (plane_out && t_owned) {
+                const long tg = tbase + (long)(pm - 1) * g.s_m;
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) g.qacc[m * a.plane + tg] = tout[m][tr][tc];
+            }
+            __syncthreads();
+        } else {
+            if (owned && plane_out) {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) g.qacc[m * a.plane + gc - g.s_m] = accM[m];
+            }
         }
 #pragma unroll
         for (int m = 0; m < MEQN; m++) { accM[m] = acc0[m]; acc0[m] = accP[m]; qc[m] = qn[m]; }
