@@ -361,12 +361,15 @@ __global__ __launch_bounds__(256) void slices3_kernel(SweepArgs a, Slices3Args t
 #define PCL_T3_SHARED_RCP 0      /* 1: spills at the 256-VGPR budget of 8 wavefronts (140 B of scratch per lane) */
 #endif
 struct P2 { double p, v; };
-template <class RP, int DIR>
+// M34: method(3) = 10*m3 + m4 as a compile-time constant (22: the solver default, every term present, no run-time
+// selects), or -1 = read at run time
+template <class RP, int DIR, int M34 = -1>
 __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], const double (&auxv)[RP::NAUX],
                                                 const double (&blkR)[3][3][RP::NAUX], const SweepArgs &a, const Slices3Args &t,
                                                 bool cfl_ok, double &cflmax, P2 &qadd, P2 &df, P2 (&G)[2][3], P2 (&H)[2][3]) {
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES, NAUX = RP::NAUX;
     using Cell = typename RP::Cell;
+    const int m3 = M34 >= 0 ? M34 / 10 : t.m3, m4 = M34 >= 0 ? M34 % 10 : t.m4;
     static_assert(NAUX == 2, "aux = (impedance, sound speed)");
     const double d = a.dtd;
     const Cell cR = RP::template precell<DIR>(q, a.par, auxv);
@@ -425,7 +428,7 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
     for (int k = 0; k < 2; k++)
 #pragma unroll
         for (int j = 0; j < 3; j++) { G[k][j].p = 0.0; G[k][j].v = 0.0; H[k][j].p = 0.0; H[k][j].v = 0.0; }
-    if (t.m3 <= 0) return;
+    if (m3 <= 0) return;
 
     // Every split below uses THIS cell's block: A^+ dq and the correction flux of interface l belong to cell l, and
     // A^- dq / the correction flux of interface l+1 -- which the dense code splits in lane l+1 with the left
@@ -466,7 +469,7 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
     split(false, 1, aM, cmamdq, cpamdq);
     split(false, 1, aP, cmapdq, cpapdq);
     P2 bmcqxxm = zero, bpcqxxm = zero, bmcqxxp = zero, bpcqxxp = zero, cmcqxxm = zero, cpcqxxm = zero, cmcqxxp = zero, cpcqxxp = zero;
-    if (t.m3 == 2) {
+    if (m3 == 2) {
         split(true, 1, kM, bmcqxxm, bpcqxxm);
         split(true, 1, kP, bmcqxxp, bpcqxxp);
         split(false, 1, kM, cmcqxxm, cpcqxxm);
@@ -481,7 +484,7 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
         double g10 = 0.0, g20 = 0.0, g21 = 0.0, g11 = 0.0, g2m = 0.0, g1m = 0.0;
         g10 = g10 - 0.5 * d * bmap;
         g20 = g20 - 0.5 * d * bpap;
-        if (t.m4 > 0) {
+        if (m4 > 0) {
             g20 = g20 + k6 * (xpcpap - xpcmap);
             g10 = g10 + k6 * (xmcpap - xmcmap);
             g21 = g21 - k6 * xpcpap;
@@ -489,13 +492,13 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
             g2m = g2m + k6 * xpcmap;
             g1m = g1m + k6 * xmcmap;
         }
-        if (t.m3 >= 2) {
+        if (m3 >= 2) {
             g20 = g20 + d * qpp;
             g10 = g10 + d * qmp;
         }
         g10 = g10 - 0.5 * d * bmam;                 // interface l+1
         g20 = g20 - 0.5 * d * bpam;
-        if (t.m4 > 0) {
+        if (m4 > 0) {
             g20 = g20 + k6 * (xpcpam - xpcmam);
             g10 = g10 + k6 * (xmcpam - xmcmam);
             g21 = g21 - k6 * xpcpam;
@@ -503,7 +506,7 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
             g2m = g2m + k6 * xpcmam;
             g1m = g1m + k6 * xmcmam;
         }
-        if (t.m3 >= 2) {
+        if (m3 >= 2) {
             g20 = g20 - d * qpm;
             g10 = g10 - d * qmm;
         }
@@ -512,11 +515,11 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
     {   // ---- G fluxes (y-like), flux3.f:347-452: the z-like splits (corrected by the correction waves' for m4 = 2)
         // split again in the y-like direction, inside the z-like row they went to
         P2 bmcpapdq = zero, bpcpapdq = zero, bmcpamdq = zero, bpcpamdq = zero, bmcmapdq = zero, bpcmapdq = zero, bmcmamdq = zero, bpcmamdq = zero;
-        if (t.m4 > 0) {
-            const double cpapdq2 = t.m4 == 2 ? cpapdq.p - 3.0 * cpcqxxp.p : cpapdq.p;
-            const double cpamdq2 = t.m4 == 2 ? cpamdq.p + 3.0 * cpcqxxm.p : cpamdq.p;
-            const double cmapdq2 = t.m4 == 2 ? cmapdq.p - 3.0 * cmcqxxp.p : cmapdq.p;
-            const double cmamdq2 = t.m4 == 2 ? cmamdq.p + 3.0 * cmcqxxm.p : cmamdq.p;
+        if (m4 > 0) {
+            const double cpapdq2 = m4 == 2 ? cpapdq.p - 3.0 * cpcqxxp.p : cpapdq.p;
+            const double cpamdq2 = m4 == 2 ? cpamdq.p + 3.0 * cpcqxxm.p : cpamdq.p;
+            const double cmapdq2 = m4 == 2 ? cmapdq.p - 3.0 * cmcqxxp.p : cmapdq.p;
+            const double cmamdq2 = m4 == 2 ? cmamdq.p + 3.0 * cmcqxxm.p : cmamdq.p;
             split(true, 2, cpapdq2, bmcpapdq, bpcpapdq);
             split(true, 2, cpamdq2, bmcpamdq, bpcpamdq);
             split(true, 0, cmapdq2, bmcmapdq, bpcmapdq);
@@ -531,11 +534,11 @@ __device__ __forceinline__ void slice3_pieces_p(const double (&q)[RP::MEQN], con
     }
     {   // ---- H fluxes (z-like), flux3.f:462-590: the y-like splits (corrected for m4 = 2) split again in the z-like direction
         P2 ymcpapdq = zero, ypcpapdq = zero, ymcpamdq = zero, ypcpamdq = zero, ymcmapdq = zero, ypcmapdq = zero, ymcmamdq = zero, ypcmamdq = zero;
-        if (t.m4 > 0) {
-            const double bpapdq2 = t.m4 == 2 ? bpapdq.p - 3.0 * bpcqxxp.p : bpapdq.p;
-            const double bpamdq2 = t.m4 == 2 ? bpamdq.p + 3.0 * bpcqxxm.p : bpamdq.p;
-            const double bmapdq2 = t.m4 == 2 ? bmapdq.p - 3.0 * bmcqxxp.p : bmapdq.p;
-            const double bmamdq2 = t.m4 == 2 ? bmamdq.p + 3.0 * bmcqxxm.p : bmamdq.p;
+        if (m4 > 0) {
+            const double bpapdq2 = m4 == 2 ? bpapdq.p - 3.0 * bpcqxxp.p : bpapdq.p;
+            const double bpamdq2 = m4 == 2 ? bpamdq.p + 3.0 * bpcqxxm.p : bpamdq.p;
+            const double bmapdq2 = m4 == 2 ? bmapdq.p - 3.0 * bmcqxxp.p : bmapdq.p;
+            const double bmamdq2 = m4 == 2 ? bmamdq.p + 3.0 * bmcqxxm.p : bmamdq.p;
             split(false, 2, bpapdq2, ymcpapdq, ypcpapdq);
             split(false, 2, bpamdq2, ymcpamdq, ypcpamdq);
             split(false, 0, bmapdq2, ymcmapdq, ypcmapdq);
@@ -766,7 +769,7 @@ __device__ __forceinline__ void pair3p(int oe, int of, double dty, double dtz, c
 // march3_kernel for the pressure-driven form (slice3_pieces_p): component 0 receives both addends of every contribution,
 // the y-like velocity only A, the z-like velocity only B, the sweep velocity only the slice's own qadd / fadd -- 24
 // doubles per lane cross wavefronts instead of 48, in ONE exchange phase (two barriers per march step).
-template <class RP, int DIR, int NW>
+template <class RP, int DIR, int NW, int M34 = -1>
 __global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3Args t, March3Args g) {
     constexpr int MEQN = RP::MEQN, NAUX = RP::NAUX;
     static_assert(MEQN == 4 && RP::T3_PRESSURE, "q = (p, u, v, w)");
@@ -890,7 +893,7 @@ __global__ __launch_bounds__(NW *WAVE) void march3p_kernel(SweepArgs a, Slices3A
             double auxv[NAUX];
 #pragma unroll
             for (int k = 0; k < NAUX; k++) auxv[k] = blkR[1][1][k];
-            slice3_pieces_p<RP, DIR>(qc, auxv, blkR, a, t, cfl_ok, cflmax, qadd, df, G, H);
+            slice3_pieces_p<RP, DIR, M34>(qc, auxv, blkR, a, t, cfl_ok, cflmax, qadd, df, G, H);
         } else {
 #pragma unroll
             for (int k = 0; k < 2; k++)

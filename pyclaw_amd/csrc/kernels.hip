@@ -172,7 +172,9 @@ template <class RP, int DIR> int launch_unsplit3_t(const Unsplit3Launch &l, std:
                                l.stream, a.qin, l.qacc, (int)RP::MEQN, a.plane, I, J, K, l.s_e, a.mbc);
         }
         static const int dense = [] { const char *e = getenv("PCL_TUNE_UNSPLIT3_DENSE"); return e ? atoi(e) : 0; }();
-        if (RP::T3_PRESSURE && !dense)
+        if (RP::T3_PRESSURE && !dense && l.m3 == 2 && l.m4 == 2)      // the solver default, method(3) = 22, as constants
+            hipLaunchKernelGGL((march3p_kernel<RP, DIR, NW, 22>), dim3((unsigned)(per * nseg)), dim3(NW * WAVE), 0, l.stream, a, t, g);
+        else if (RP::T3_PRESSURE && !dense)
             hipLaunchKernelGGL((march3p_kernel<RP, DIR, NW>), dim3((unsigned)(per * nseg)), dim3(NW * WAVE), 0, l.stream, a, t, g);
         else
             hipLaunchKernelGGL((march3_kernel<RP, DIR, NW>), dim3((unsigned)(per * nseg)), dim3(NW * WAVE), 0, l.stream, a, t, g);
