@@ -1,0 +1,202 @@
+// classic_fused.hpp -- the dimension-split 2-D step (step2ds.f: x sweeps of every row, then y sweeps of every
+// column of the x-swept array) in ONE kernel: q moves through HBM once per STEP instead of once per pass.
+//
+// Reference path: src/fortran/2d/classic/step2ds.f:83-159 (both loops), flux2.f, limiter.f; boundary conditions as
+// the x pass of sweep_kernel evaluates them while loading (solver.py:354-452), the app's radial source applied to the
+// finished cell while storing (clawpack.py:156-159) -- the same lane_core, the same order of operations, the same bits
+// as the two-pass form (classic.hpp), which stays the path for decomposed blocks, capacity functions, aux-carrying
+// Riemann solvers and mbc != 2.
+//
+// Tile: 32 rows x 64 columns of q with a 2-cell halo on every side, all MEQN planes in LDS (Euler: 80 KB, two
+// workgroups per CU).  Three phases, one barrier between them:
+//   load   the tile, ghost cells remapped to their boundary-condition source cells (tiles on the frame only);
+//   x      wavefront w sweeps rows w, w+8, w+16, w+24: one lane = one cell, the row is a 64-lane strip exactly as in
+//          the x pass; the 60 inner lanes put the updated cell back IN PLACE (interior columns only: ghost columns
+//          are copied through, step2ds.f:141-146).  All 32 rows are swept: the y sweeps below need q* two rows beyond
+//          the rows they update;
+//   y      a wavefront takes TWO columns at a time, 32 rows each (lanes 0..31 / 32..63 = the rows of column c / c+1;
+//          the wavefront shifts between lanes 31 and 32 only feed halo rows): rows 2..29 of the interior columns put
+//          the finished cell back in place;
+//   store  rows 2..29 x columns 2..61 (interior cells only), 16 bytes per lane.
+// HBM traffic per cell and step: (32*64)/(28*60) reads + 1 write of q = 88.8 B for Euler instead of 2 x 82.5 B.
+// The halo rows / columns are computed twice (x phase 32/28, y phase 32/28 lanes): +14 % arithmetic, which the
+// wave-uniform no-jump shortcut of lane_core makes cheap wherever the gas is undisturbed.
+// LDS layout: row-major rows of 64 doubles, the column XOR-swizzled with the row: the x phase (lanes = columns)
+// touches 64 consecutive doubles, the y phase (lanes = rows) 32 distinct 8-byte banks per half-wave.
+#pragma once
+#include "classic.hpp"
+
+namespace pcl {
+namespace PCL_NS {
+
+constexpr int F_ROWS = 32, F_COLS = WAVE;
+constexpr int F_OWN_R = F_ROWS - 2 * HALO, F_OWN_C = F_COLS - 2 * HALO;
+constexpr int F_THREADS = 512, F_WAVES = F_THREADS / WAVE;
+
+__device__ __forceinline__ int ftile_at(int m, int r, int c) { return (m * F_ROWS + r) * F_COLS + (c ^ r); }
+
+template <class RP, bool FWAVE, bool SRC>
+__global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kernel(SweepArgs a, int ntx, int nty) {
+    constexpr int MEQN = RP::MEQN;
+    static_assert(RP::NAUX == 0, "solvers without aux arrays");
+    static_assert(!SRC || MEQN == 5, "fused source: the Euler solver");
+    __shared__ __attribute__((aligned(16))) double tile[MEQN * F_ROWS * F_COLS];
+
+    const int bid = xcd_logical_block(a.xcd);
+    const int tx = bid % ntx, ty = bid / ntx;
+    const int x0 = a.mbc - HALO + tx * F_OWN_C;      // array column of tile column 0 (a.mbc == HALO: checked by the launcher)
+    const int y0 = a.mbc - HALO + ty * F_OWN_R;
+
+    // ---- load ----------------------------------------------------------------------------------------------------
+    const bool full_tile = x0 + F_COLS <= a.I && y0 + F_ROWS <= a.J;
+    const bool vbc_tile = a.vbc_on && ((x0 < a.mbc && a.vbc[0] >= 0) || (x0 + F_COLS > a.I - a.mbc && a.vbc[1] >= 0) ||
+                                       (y0 < a.mbc && a.vbc[2] >= 0) || (y0 + F_ROWS > a.J - a.mbc && a.vbc[3] >= 0));
+    if (full_tile && !vbc_tile) {
+#pragma unroll
+        for (int k = 0; k < F_ROWS * F_COLS / 2 / F_THREADS; k++) {
+            const int slot = threadIdx.x + F_THREADS * k;
+            const int r = slot / (F_COLS / 2), c = 2 * (slot % (F_COLS / 2));
+            const long g = (long)(y0 + r) * a.pitch + (x0 + c);
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) {
+                double2 v = *reinterpret_cast<const double2 *>(&a.qin[m * a.plane + g]);
+                if (r & 1) { const double t = v.x; v.x = v.y; v.y = t; }       // the swizzle swaps the pair in odd rows
+                *reinterpret_cast<double2 *>(&tile[(m * F_ROWS + r) * F_COLS + ((c ^ r) & ~1)]) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < F_ROWS * F_COLS / F_THREADS; k++) {
+            const int slot = threadIdx.x + F_THREADS * k;
+            const int r = slot / F_COLS, c = slot % F_COLS;
+            int gx = x0 + c, gy = y0 + r;
+            gx = gx < a.I ? gx : a.I - 1;            // past the edge: repeat the last cell (never feeds a stored value)
+            gy = gy < a.J ? gy : a.J - 1;
+            if (vbc_tile) {
+                // qbc = Y(X(q)): x sides first, then y sides over the x-filled array (solver.py:354-381)
+                const VbcMap mi = vbc_map(gx, a.I, a.mbc, a.vbc[0], a.vbc[1]);
+                const VbcMap mj = vbc_map(gy, a.J, a.mbc, a.vbc[2], a.vbc[3]);
+                const long gs = (long)mj.src * a.pitch + mi.src;
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) {
+                    double v = a.qin[m * a.plane + gs];
+                    if (m == 1) v = mi.neg ? -v : v;
+                    const double cx = mi.side ? a.vconst[1][m] : a.vconst[0][m];
+                    v = mi.cst ? cx : v;
+                    if (m == 2) v = mj.neg ? -v : v;
+                    const double cy = mj.side ? a.vconst[3][m] : a.vconst[2][m];
+                    v = mj.cst ? cy : v;
+                    tile[ftile_at(m, r, c)] = v;
+                }
+            } else {
+                const long g = (long)gy * a.pitch + gx;
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) tile[ftile_at(m, r, c)] = a.qin[m * a.plane + g];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    double cflx = 0.0, cfly = 0.0;
+
+    // ---- x sweeps of the tile's rows (step2ds.f:83-146) --------------------------------------------------------
+    {
+        const int ca = x0 + lane;
+        const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.mx) && lane >= HALO && lane < WAVE - HALO;
+        const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.mx) && lane >= 1;
+#pragma unroll 1
+        for (int r = wv; r < F_ROWS; r += F_WAVES) {
+            if (y0 + r >= a.J) break;                 // wave-uniform
+            double q[MEQN], qn[MEQN];
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, r, lane)];
+            lane_core<RP, 1, false, FWAVE, false>(q, a.dtd, 1.0, cfl_ok, a, qn, cflx);
+            if (owned) {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) tile[ftile_at(m, r, lane)] = qn[m];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- y sweeps of the tile's columns (step2ds.f:150-159), two columns per wavefront --------------------------
+    {
+        SweepArgs ay = a;
+        ay.dtd = a.dtd_t;
+        const int rl = lane & (F_ROWS - 1), h = lane / F_ROWS;
+        const int gy = y0 + rl;
+        const bool row_owned = (gy >= a.mbc) && (gy < a.mbc + a.my) && rl >= HALO && rl < F_ROWS - HALO;
+        const bool row_cfl = (gy >= a.mbc) && (gy <= a.mbc + a.my) && rl >= 1;
+#pragma unroll 1
+        for (int p = wv; p < F_COLS / 2; p += F_WAVES) {
+            const int c = 2 * p + h, gx = x0 + c;
+            // columns that hold q*: the tile's own interior columns and every ghost column (copied through by the x
+            // sweeps; step2ds sweeps them too and their wave speeds count for the Courant number)
+            auto has_qstar = [&](int cc) {
+                const int g = x0 + cc;
+                return g < a.I && ((cc >= HALO && cc < F_COLS - HALO) || g < a.mbc || g >= a.mbc + a.mx);
+            };
+            if (!has_qstar(2 * p) && !has_qstar(2 * p + 1)) continue;      // wave-uniform
+            const bool col_ok = has_qstar(c);
+            const bool col_int = c >= HALO && c < F_COLS - HALO && gx >= a.mbc && gx < a.mbc + a.mx;
+            double q[MEQN], qn[MEQN];
+#pragma unroll
+            for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, rl, c)];
+            lane_core<RP, 2, false, FWAVE, false>(q, ay.dtd, 1.0, row_cfl && col_ok, ay, qn, cfly);
+            if (row_owned && col_int) {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) tile[ftile_at(m, rl, c)] = qn[m];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- store: the tile's own interior cells --------------------------------------------------------------------
+    const bool all_interior = full_tile && x0 + HALO >= a.mbc && x0 + HALO + F_OWN_C <= a.mbc + a.mx && y0 + HALO >= a.mbc &&
+                              y0 + HALO + F_OWN_R <= a.mbc + a.my;
+    if (all_interior) {
+        constexpr int PAIRS = F_OWN_C / 2, SLOTS = PAIRS * F_OWN_R;
+#pragma unroll
+        for (int k = 0; k < (SLOTS + F_THREADS - 1) / F_THREADS; k++) {
+            const int slot = threadIdx.x + F_THREADS * k;
+            if (slot < SLOTS) {
+                const int r = HALO + slot / PAIRS, c = HALO + 2 * (slot % PAIRS);
+                const long g = (long)(y0 + r) * a.pitch + (x0 + c);
+                double2 v[MEQN];
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) {
+                    v[m] = *reinterpret_cast<const double2 *>(&tile[(m * F_ROWS + r) * F_COLS + ((c ^ r) & ~1)]);
+                    if (r & 1) { const double t = v[m].x; v[m].x = v[m].y; v[m].y = t; }
+                }
+                if constexpr (SRC) {
+                    const double2 rad = *reinterpret_cast<const double2 *>(&a.aux[g]);
+                    euler_radial_source(v[0].x, v[1].x, v[2].x, v[3].x, rad.x, a.dt, a.src_p[0], a.src_p[1]);
+                    euler_radial_source(v[0].y, v[1].y, v[2].y, v[3].y, rad.y, a.dt, a.src_p[0], a.src_p[1]);
+                }
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) st_stream2(&a.qout[m * a.plane + g], v[m]);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int slot = threadIdx.x; slot < F_OWN_R * F_OWN_C; slot += F_THREADS) {
+            const int r = HALO + slot / F_OWN_C, c = HALO + slot % F_OWN_C;
+            const int gx = x0 + c, gy = y0 + r;
+            if (gx >= a.mbc && gx < a.mbc + a.mx && gy >= a.mbc && gy < a.mbc + a.my) {
+                const long g = (long)gy * a.pitch + gx;
+                double v[MEQN];
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) v[m] = tile[ftile_at(m, r, c)];
+                if constexpr (SRC) euler_radial_source(v[0], v[1], v[2], v[3], a.aux[g], a.dt, a.src_p[0], a.src_p[1]);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) a.qout[m * a.plane + g] = v[m];
+            }
+        }
+    }
+    // the two passes have their own dt/d: the larger Courant number of the two is the step's (step2ds.f:136,181)
+    cfl_publish(a.cfl, dmax(cfl_value<false>(cflx, a.dtd), cfl_value<false>(cfly, a.dtd_t)));
+}
+
+}  // namespace PCL_NS
+}  // namespace pcl

@@ -13,6 +13,7 @@
 #include "classic.hpp"
 #include "sharpclaw.hpp"
 #include "classic3.hpp"
+#include "classic_fused.hpp"
 
 namespace pcl {
 namespace PCL_NS {
@@ -107,6 +108,39 @@ int launch_sweep(const SweepLaunch &l, std::string &err) {
         if (rp == PCL_RP_EULER5_2D) return launch<Euler5, 2, false>(l, err);
     }
     err = "Riemann solver id is not a 2-D solver";
+    return PCL_EINVAL;
+}
+
+// the whole dimension-split 2-D step, qin -> qout (classic_fused.hpp); l.a as for the x pass + a.dtd_t = dt/dy and
+// a.src_id of the step.  The host (pclaw.hip: fused_step_ok) only sends what the kernel covers.
+namespace {
+template <class RP> int launch_step2ds_t(const SweepLaunch &l, std::string &err) {
+    const SweepArgs &a = l.a;
+    constexpr bool FW = IsFwave<RP>::value;
+    if ((l.fwave != 0) != FW) { err = "solver.fwave does not match the Riemann solver"; return PCL_EINVAL; }
+    if (a.mbc != HALO || a.mcapa > 0) { err = "step2ds kernel: mbc = 2, no capacity function"; return PCL_EINVAL; }
+    const int ntx = (a.mx + F_OWN_C - 1) / F_OWN_C, nty = (a.my + F_OWN_R - 1) / F_OWN_R;
+    const dim3 grid((unsigned)ntx * (unsigned)nty);
+    if (a.src_id != 0) {
+        if constexpr (std::is_same<RP, Euler5>::value) {
+            if (a.src_id != 1) { err = "fused source: Euler radial source"; return PCL_EINVAL; }
+            hipLaunchKernelGGL((step2ds_kernel<RP, FW, true>), grid, dim3(F_THREADS), 0, l.stream, a, ntx, nty);
+        } else {
+            err = "fused source: only the Euler solver has it";
+            return PCL_EINVAL;
+        }
+    } else
+        hipLaunchKernelGGL((step2ds_kernel<RP, FW, false>), grid, dim3(F_THREADS), 0, l.stream, a, ntx, nty);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PCL_OK : hip_fail(err, "step2ds launch", e);
+}
+}  // namespace
+int launch_step2ds(const SweepLaunch &l, std::string &err) {
+    if (l.rp == PCL_RP_EULER5_2D) return launch_step2ds_t<Euler5>(l, err);
+    if (l.rp == PCL_RP_ACOUSTICS_2D) return launch_step2ds_t<Acoustics2D>(l, err);
+    if (l.rp == PCL_RP_ADVECTION_2D) return launch_step2ds_t<Advection2D>(l, err);
+    if (l.rp == PCL_RP_SHALLOW_2D) return launch_step2ds_t<Shallow2D>(l, err);
+    err = "step2ds kernel: Riemann solvers without aux arrays only";
     return PCL_EINVAL;
 }
 

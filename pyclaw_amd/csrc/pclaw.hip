@@ -434,6 +434,46 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
     return rc;
 }
 
+// The dimension-split 2-D step as ONE kernel (classic_fused.hpp): one block, two ghost layers, Riemann solvers without
+// aux arrays, no capacity function.  PCL_TUNE_FUSED_STEP=0 keeps the two passes.
+bool fused_step_ok(const pcl_solver *s) {
+    static const int on = [] { const char *e = getenv("PCL_TUNE_FUSED_STEP"); return e ? atoi(e) : 1; }();
+    const int rp = s->cfg.rp;
+    return on && s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.mbc == 2 && s->cfg.method[5] <= 0 && !s->halo.active &&
+           s->cfg.meqn <= 5 &&
+           (rp == PCL_RP_EULER5_2D || rp == PCL_RP_ACOUSTICS_2D || rp == PCL_RP_ADVECTION_2D || rp == PCL_RP_SHALLOW_2D);
+}
+int do_step2ds(pcl_solver *s, const double *qin, double *qout, double dt) {
+    SweepArgs a = make_args(s, qin, qout, 1, dt);
+    a.dtd_t = dt / s->cfg.d[1];
+    a.src_id = s->fused_src;
+    pcl_solver::Timed t{};
+    const bool timed = timing_on(s);
+    if (timed) {
+        t.a = get_event(s);
+        t.b = get_event(s);
+        t.which = 0;
+        t.count = true;
+        hipEventRecord(t.a, s->stream);
+    }
+    SweepLaunch l;
+    l.a = a;
+    l.ndim = 2;
+    l.rp = s->cfg.rp;
+    l.ids = 1;
+    l.fwave = s->cfg.fwave;
+    l.stream = s->stream;
+    std::string err;
+    int rc = PCL_BY_MATH(s->cfg.math, launch_step2ds(l, err));
+    if (rc) fail(rc, err);
+    if (timed) {
+        hipEventRecord(t.b, s->stream);
+        s->timed.push_back(t);
+        if (s->timed.size() >= 2048) drain_timing(s);
+    }
+    return rc;
+}
+
 // 3-D dimension-split sweep along dir (1..3), qin -> qout (step3ds.f; kernel in classic.hpp)
 int do_sweep3(pcl_solver *s, const double *qin, double *qout, int dir, double dt) {
     SweepArgs a = make_args(s, qin, qout, 1, dt);
@@ -1074,8 +1114,12 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
         std::swap(s->q, s->t1);
         s->undo_slot = &s->t1;
     } else if (s->cfg.method[2] < 0) {  // dimensional splitting, clawpack.py:538-546
-        if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return bail(s, rc);
-        if (int rc = do_sweep(s, s->t1, s->t2, 2, dt)) return bail(s, rc);
+        if (fused_step_ok(s)) {
+            if (int rc = do_step2ds(s, s->q, s->t2, dt)) return bail(s, rc);
+        } else {
+            if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return bail(s, rc);
+            if (int rc = do_sweep(s, s->t1, s->t2, 2, dt)) return bail(s, rc);
+        }
         std::swap(s->q, s->t2);
         s->undo_slot = &s->t2;
     } else {  // unsplit, clawpack.py:550-552 -> step2.f

@@ -142,6 +142,7 @@ struct SweepLaunch {
 // defined in kernels.hip, once per arithmetic mode; returns 0 or a PCL_E* code + message
 namespace exact {
 int launch_sweep(const SweepLaunch &l, std::string &err);
+int launch_step2ds(const SweepLaunch &l, std::string &err);   // whole dim-split 2-D step in one kernel (classic_fused.hpp)
 // x-pass tiles [tb_lo,tb_hi) x [ta_lo,ta_hi) that read no ghost cell; false if there are none
 // ntiles[0], ntiles[1] = row tiles / tiles along a row of the x pass
 bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]);
@@ -153,6 +154,7 @@ int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 }
 namespace fast {
 int launch_sweep(const SweepLaunch &l, std::string &err);
+int launch_step2ds(const SweepLaunch &l, std::string &err);   // whole dim-split 2-D step in one kernel (classic_fused.hpp)
 int launch_sweep3(const SweepLaunch &l, std::string &err);
 int launch_unsplit3(const Unsplit3Launch &l, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase
@@ -162,6 +164,7 @@ int launch_rk(const RkLaunch &r, hipStream_t stream, std::string &err);
 // exact + IEEE quotients for underflow-range numerators as well (rp.hpp PCL_DENORM_GUARD), PCL_MATH_STRICT
 namespace strict {
 int launch_sweep(const SweepLaunch &l, std::string &err);
+int launch_step2ds(const SweepLaunch &l, std::string &err);   // whole dim-split 2-D step in one kernel (classic_fused.hpp)
 int launch_sweep3(const SweepLaunch &l, std::string &err);
 int launch_unsplit3(const Unsplit3Launch &l, std::string &err);
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);
