@@ -33,6 +33,9 @@ constexpr int F_ROWS = 32, F_COLS = WAVE;
 constexpr int F_OWN_R = F_ROWS - 2 * HALO, F_OWN_C = F_COLS - 2 * HALO;
 constexpr int F_THREADS = 512, F_WAVES = F_THREADS / WAVE;
 
+#ifndef PCL_FUSED_NT      /* 1: the tile loads bypass the caches like the two-pass kernels' (A/B) */
+#define PCL_FUSED_NT 0
+#endif
 __device__ __forceinline__ int ftile_at(int m, int r, int c) { return (m * F_ROWS + r) * F_COLS + (c ^ r); }
 
 template <class RP, bool FWAVE, bool SRC>
@@ -42,8 +45,33 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
     static_assert(!SRC || MEQN == 5, "fused source: the Euler solver");
     __shared__ __attribute__((aligned(16))) double tile[MEQN * F_ROWS * F_COLS];
 
-    const int bid = xcd_logical_block(a.xcd);
-    const int tx = bid % ntx, ty = bid / ntx;
+    int bid = xcd_logical_block(a.xcd);
+    int tx = bid % ntx, ty = bid / ntx;
+    if (a.sub != 0) {
+        // decomposed block (pclaw.hip): the tiles inside box = [ty_lo, ty_hi) x [tx_lo, tx_hi) read no ghost cell a
+        // neighbour block has to send -- sub 1 = those (they run beside the halo exchange), 2 = the others
+        const int bw = a.box[3] - a.box[2];
+        if (a.sub == 1) {
+            ty = a.box[0] + bid / bw;
+            tx = a.box[2] + bid % bw;
+        } else {
+            const int top = a.box[0] * ntx, bot = (nty - a.box[1]) * ntx;
+            if (bid < top) {
+                ty = bid / ntx;
+                tx = bid % ntx;
+            } else if (bid < top + bot) {
+                bid -= top;
+                ty = a.box[1] + bid / ntx;
+                tx = bid % ntx;
+            } else {
+                bid -= top + bot;
+                const int side = ntx - bw;
+                const int k = bid % side;
+                ty = a.box[0] + bid / side;
+                tx = k < a.box[2] ? k : a.box[3] + (k - a.box[2]);
+            }
+        }
+    }
     const int x0 = a.mbc - HALO + tx * F_OWN_C;      // array column of tile column 0 (a.mbc == HALO: checked by the launcher)
     const int y0 = a.mbc - HALO + ty * F_OWN_R;
 
@@ -59,7 +87,11 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
             const long g = (long)(y0 + r) * a.pitch + (x0 + c);
 #pragma unroll
             for (int m = 0; m < MEQN; m++) {
+#if PCL_FUSED_NT
+                double2 v = ld_stream2(&a.qin[m * a.plane + g]);
+#else
                 double2 v = *reinterpret_cast<const double2 *>(&a.qin[m * a.plane + g]);
+#endif
                 if (r & 1) { const double t = v.x; v.x = v.y; v.y = t; }       // the swizzle swaps the pair in odd rows
                 *reinterpret_cast<double2 *>(&tile[(m * F_ROWS + r) * F_COLS + ((c ^ r) & ~1)]) = v;
             }
@@ -111,7 +143,11 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
             double q[MEQN], qn[MEQN];
 #pragma unroll
             for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, r, lane)];
-            lane_core<RP, 1, false, FWAVE, false>(q, a.dtd, 1.0, cfl_ok, a, qn, cflx);
+            if (a.ablate & 1) {      // diagnostic (tools/kbench.py): the kernel's memory traffic without its arithmetic
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) qn[m] = q[m];
+            } else
+                lane_core<RP, 1, false, FWAVE, false>(q, a.dtd, 1.0, cfl_ok, a, qn, cflx);
             if (owned) {
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) tile[ftile_at(m, r, lane)] = qn[m];
@@ -143,7 +179,11 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
             double q[MEQN], qn[MEQN];
 #pragma unroll
             for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, rl, c)];
-            lane_core<RP, 2, false, FWAVE, false>(q, ay.dtd, 1.0, row_cfl && col_ok, ay, qn, cfly);
+            if (a.ablate & 1) {
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) qn[m] = q[m];
+            } else
+                lane_core<RP, 2, false, FWAVE, false>(q, ay.dtd, 1.0, row_cfl && col_ok, ay, qn, cfly);
             if (row_owned && col_int) {
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) tile[ftile_at(m, rl, c)] = qn[m];

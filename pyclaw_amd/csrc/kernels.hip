@@ -120,7 +120,17 @@ template <class RP> int launch_step2ds_t(const SweepLaunch &l, std::string &err)
     if ((l.fwave != 0) != FW) { err = "solver.fwave does not match the Riemann solver"; return PCL_EINVAL; }
     if (a.mbc != HALO || a.mcapa > 0) { err = "step2ds kernel: mbc = 2, no capacity function"; return PCL_EINVAL; }
     const int ntx = (a.mx + F_OWN_C - 1) / F_OWN_C, nty = (a.my + F_OWN_R - 1) / F_OWN_R;
-    const dim3 grid((unsigned)ntx * (unsigned)nty);
+    unsigned nblocks = (unsigned)ntx * (unsigned)nty;
+    if (a.sub != 0) {
+        if (a.box[0] < 0 || a.box[1] > nty || a.box[2] < 0 || a.box[3] > ntx || a.box[0] >= a.box[1] || a.box[2] >= a.box[3]) {
+            err = "step2ds tile subset: bad box";
+            return PCL_EINVAL;
+        }
+        const unsigned inside = (unsigned)(a.box[1] - a.box[0]) * (unsigned)(a.box[3] - a.box[2]);
+        nblocks = a.sub == 1 ? inside : nblocks - inside;
+        if (nblocks == 0) return PCL_OK;
+    }
+    const dim3 grid(nblocks);
     if (a.src_id != 0) {
         if constexpr (std::is_same<RP, Euler5>::value) {
             if (a.src_id != 1) { err = "fused source: Euler radial source"; return PCL_EINVAL; }
@@ -248,6 +258,20 @@ int launch_unsplit3(const Unsplit3Launch &l, std::string &err) {
 }
 
 #if !PCL_FAST
+// the same for the one-kernel step (classic_fused.hpp): tile (ty, tx) reads rows mbc-2+28*ty .. +31 and columns
+// mbc-2+60*tx .. +63; box = [ty_lo, ty_hi) x [tx_lo, tx_hi), ntiles = (nty, ntx)
+bool step2ds_interior_box(const SweepArgs &a, int box[4], int ntiles[2]) {
+    const int ntx = (a.mx + F_OWN_C - 1) / F_OWN_C, nty = (a.my + F_OWN_R - 1) / F_OWN_R;
+    box[0] = 1;
+    const int roomy = a.my + HALO - F_ROWS;       // 28*ty + 32 <= my + 2
+    box[1] = roomy < 0 ? 0 : std::min(nty, roomy / F_OWN_R + 1);
+    box[2] = 1;
+    const int roomx = a.mx + HALO - F_COLS;
+    box[3] = roomx < 0 ? 0 : std::min(ntx, roomx / F_OWN_C + 1);
+    ntiles[0] = nty;
+    ntiles[1] = ntx;
+    return box[0] < box[1] && box[2] < box[3];
+}
 bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]) {
     using T = TileShape<1>;
     constexpr int ADV = T::NSTRIP * STRIP;  // cells a tile advances along the row

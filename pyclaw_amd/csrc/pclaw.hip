@@ -434,27 +434,31 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
     return rc;
 }
 
-// The dimension-split 2-D step as ONE kernel (classic_fused.hpp): one block, two ghost layers, Riemann solvers without
-// aux arrays, no capacity function.  PCL_TUNE_FUSED_STEP=0 keeps the two passes.
+// The dimension-split 2-D step as ONE kernel (classic_fused.hpp): two ghost layers, Riemann solvers without aux
+// arrays, no capacity function.  PCL_TUNE_FUSED_STEP=0 keeps the two passes.
+// sub/box: tile subset (interior / rim of a decomposed block), `on`: the halo stream for the rim launch.
 bool fused_step_ok(const pcl_solver *s) {
     static const int on = [] { const char *e = getenv("PCL_TUNE_FUSED_STEP"); return e ? atoi(e) : 1; }();
     const int rp = s->cfg.rp;
-    return on && s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.mbc == 2 && s->cfg.method[5] <= 0 && !s->halo.active &&
-           s->cfg.meqn <= 5 &&
+    return on && s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.mbc == 2 && s->cfg.method[5] <= 0 && s->cfg.meqn <= 5 &&
            (rp == PCL_RP_EULER5_2D || rp == PCL_RP_ACOUSTICS_2D || rp == PCL_RP_ADVECTION_2D || rp == PCL_RP_SHALLOW_2D);
 }
-int do_step2ds(pcl_solver *s, const double *qin, double *qout, double dt) {
+int do_step2ds(pcl_solver *s, const double *qin, double *qout, double dt, int sub = 0, const int *box = nullptr,
+               hipStream_t on = nullptr) {
+    hipStream_t stream = on ? on : s->stream;
     SweepArgs a = make_args(s, qin, qout, 1, dt);
     a.dtd_t = dt / s->cfg.d[1];
     a.src_id = s->fused_src;
+    a.sub = sub;
+    if (sub) for (int k = 0; k < 4; k++) a.box[k] = box[k];
     pcl_solver::Timed t{};
-    const bool timed = timing_on(s);
+    const bool timed = timing_on(s) && !on;
     if (timed) {
         t.a = get_event(s);
         t.b = get_event(s);
         t.which = 0;
-        t.count = true;
-        hipEventRecord(t.a, s->stream);
+        t.count = sub != 2;
+        hipEventRecord(t.a, stream);
     }
     SweepLaunch l;
     l.a = a;
@@ -462,12 +466,12 @@ int do_step2ds(pcl_solver *s, const double *qin, double *qout, double dt) {
     l.rp = s->cfg.rp;
     l.ids = 1;
     l.fwave = s->cfg.fwave;
-    l.stream = s->stream;
+    l.stream = stream;
     std::string err;
     int rc = PCL_BY_MATH(s->cfg.math, launch_step2ds(l, err));
     if (rc) fail(rc, err);
     if (timed) {
-        hipEventRecord(t.b, s->stream);
+        hipEventRecord(t.b, stream);
         s->timed.push_back(t);
         if (s->timed.size() >= 2048) drain_timing(s);
     }
@@ -1151,8 +1155,16 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     // Decomposed dim-split 2-D step: the halo exchange runs on its own stream while the x pass does the
     // tiles that read no ghost cell; the rim tiles follow once the ghost frame has arrived.
     int box[4], ntiles[2];
-    const bool overlapped = s->halo.active && fused && s->cfg.ndim == 2 && s->overlap && s->sel == 0 &&
-                            pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, dt), box, ntiles);
+    // both sweeps in one kernel (its own, taller tiles) where such tiles leave an interior; thin blocks keep the x pass'
+    // 4-row tiles for the overlap
+    bool onek = fused_step_ok(s), overlapped = false;
+    if (s->halo.active && fused && s->cfg.ndim == 2 && s->overlap && s->sel == 0) {
+        if (onek && pcl::exact::step2ds_interior_box(make_args(s, s->q, s->t2, 1, dt), box, ntiles)) overlapped = true;
+        else {
+            onek = false;
+            overlapped = pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, dt), box, ntiles);
+        }
+    }
     if (!overlapped) s->ghosts_drop_all();       // exchange-ahead lives in the overlapped dimension-split step only
     if (overlapped) {
         // a side without a neighbour block gets its ghost cells from the boundary conditions the kernel evaluates
@@ -1208,10 +1220,15 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
         std::string err;
         int rc;
         s->vbc_on = 1;
+        // the x pass of the two-pass step, or the whole step where one kernel does both sweeps
+        auto first = [&](int sub, hipStream_t on) {
+            return onek ? do_step2ds(s, s->q, s->t2, dt, sub, box, on) : do_sweep(s, s->q, s->t1, 1, dt, sub, box, on);
+        };
+        if (onek) s->ghosts_drop(s->t2);             // the step writes that buffer's interior: its frame is stale
         if (s->overlap == 2) {
             // test mode (PCL_HALO_OVERLAP=2): same launches on ONE stream with the interior tiles strictly
             // BEFORE the exchange -- an interior tile that read a ghost cell would see the stale frame
-            rc = do_sweep(s, s->q, s->t1, 1, dt, 1, box);
+            rc = first(1, nullptr);
             if (!rc && s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err)) rc = fail(PCL_ECOMM, err);
         } else {
             // exchange-ahead: the previous step (or a retaken step's first attempt) already exchanged this buffer's
@@ -1229,23 +1246,25 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             // The interior tiles go FIRST: the step starts on an idle device (the host has just read the previous
             // Courant number), and the host needs some tens of microseconds to enqueue the group of Send/Recv -- with
             // the interior launch already queued the device works through that time instead of waiting for it
-            rc = do_sweep(s, s->q, s->t1, 1, dt, 1, box);      // interior tiles, concurrent with the exchange
+            rc = first(1, nullptr);      // interior tiles, concurrent with the exchange
             if (!rc && !have) {
                 if (s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err, s->hstream)) rc = fail(PCL_ECOMM, err);
                 else s->ghosts_mark(s->q);
             }
             // rim tiles (ghost frame + physical BCs) behind the exchange on ITS stream: they start as soon as
             // the frame has arrived and fill the machine next to the interior kernel's tail
-            if (!rc) rc = do_sweep(s, s->q, s->t1, 1, dt, 2, box, s->hstream);
+            if (!rc) rc = first(2, s->hstream);
             hipError_t he = hipEventRecord(s->ev_h1, s->hstream);
             if (he == hipSuccess) he = hipStreamWaitEvent(s->stream, s->ev_h1, 0);
             if (!rc && he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream join: ") + hipGetErrorString(he));
         }
-        if (!rc && s->overlap == 2) rc = do_sweep(s, s->q, s->t1, 1, dt, 2, box);
+        if (!rc && s->overlap == 2) rc = first(2, nullptr);
         s->vbc_on = 0;
         if (rc) { s->ghosts_drop_all(); return bail(s, rc); }
-        s->ghosts_drop(s->t2);                       // the y pass writes that buffer, ghost rows included
-        if (int rc2 = do_sweep(s, s->t1, s->t2, 2, dt)) { s->ghosts_drop_all(); return bail(s, rc2); }
+        if (!onek) {
+            s->ghosts_drop(s->t2);                   // the y pass writes that buffer, ghost rows included
+            if (int rc2 = do_sweep(s, s->t1, s->t2, 2, dt)) { s->ghosts_drop_all(); return bail(s, rc2); }
+        }
         std::swap(s->q, s->t2);
         s->undo_slot = &s->t2;
         if (s->exchange_ahead && s->overlap == 1) {
@@ -1951,7 +1970,8 @@ int pcl_halo_can_overlap(pcl_solver *s, int *yes) {
     if (!s || !yes) return fail(PCL_EINVAL, "null argument");
     int box[4], ntiles[2];
     *yes = s->halo.active && s->cfg.kind == PCL_KIND_CLASSIC && s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.meqn <= 8 &&
-           s->overlap == 1 && pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, 1.0), box, ntiles);
+           s->overlap == 1 && ((fused_step_ok(s) && pcl::exact::step2ds_interior_box(make_args(s, s->q, s->t2, 1, 1.0), box, ntiles)) ||
+                               pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, 1.0), box, ntiles));
     return PCL_OK;
 }
 

@@ -146,6 +146,7 @@ int launch_step2ds(const SweepLaunch &l, std::string &err);   // whole dim-split
 // x-pass tiles [tb_lo,tb_hi) x [ta_lo,ta_hi) that read no ghost cell; false if there are none
 // ntiles[0], ntiles[1] = row tiles / tiles along a row of the x pass
 bool x_interior_box(const SweepArgs &a, int box[4], int ntiles[2]);
+bool step2ds_interior_box(const SweepArgs &a, int box[4], int ntiles[2]);   // the same for the one-kernel step: (nty, ntx)
 int launch_sweep3(const SweepLaunch &l, std::string &err);   // 3-D dim-split sweep, l.ids = direction 1..3
 int launch_unsplit3(const Unsplit3Launch &l, std::string &err);   // unsplit 3-D: slices + combine of one direction
 int launch_unsplit(const SweepLaunch &l, const double *qx, std::string &err);  // scratch-free unsplit phase

@@ -10,8 +10,6 @@ import os
 import numpy as np
 import pytest
 
-os.environ["PCL_FS_SMALL"] = "1"
-
 import mp_fullsize_worker as W            # noqa: E402
 import test_gpu_c4c5 as T                # noqa: E402
 from oracle import driver as D            # noqa: E402
