@@ -1225,6 +1225,41 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             return onek ? do_step2ds(s, s->q, s->t2, dt, sub, box, on) : do_sweep(s, s->q, s->t1, 1, dt, sub, box, on);
         };
         if (onek) s->ghosts_drop(s->t2);             // the step writes that buffer's interior: its frame is stale
+        if (onek && s->overlap == 1 && s->exchange_ahead && s->ghosts_filled(s->q)) {
+            // One kernel per step and the halo of THIS state already sent ahead: the rim tiles (everything a neighbour
+            // needs of the new state, and everything that reads the ghost frame) go first, on the halo stream behind the
+            // exchange that filled the frame; the new state's halo follows them there at once -- it travels while the
+            // interior tiles, on the solver stream, are still at work, and the next step's rim tiles queue up behind
+            // it.  The step ends when both launches have finished (not the exchange).  A rejected step leaves a stale
+            // exchange on the halo stream: it touches only rim cells and the ghost frame of the buffer the retake's
+            // interior launch writes elsewhere, and the retake's rim launch is ordered behind it on that stream.
+            rc = first(2, s->hstream);
+            hipError_t he = hipEventRecord(s->ev_h1, s->hstream);
+            if (!rc) rc = first(1, nullptr);
+            if (!rc && s->halo.exchange(s->t2, s->cfg.meqn, s->pitch, s->plane, err, s->hstream)) rc = fail(PCL_ECOMM, err);
+            if (he == hipSuccess) he = hipStreamWaitEvent(s->stream, s->ev_h1, 0);
+            if (!rc && he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream join: ") + hipGetErrorString(he));
+            s->vbc_on = 0;
+            if (rc) { s->ghosts_drop_all(); return bail(s, rc); }
+            std::swap(s->q, s->t2);
+            s->undo_slot = &s->t2;
+            s->ghosts_mark(s->q);
+            return read_cfl(s, cfl);
+        }
+        if (onek && s->overlap == 1 && !s->exchange_ahead) {
+            // One kernel per step, no exchange-ahead: the exchange runs in front of the step on the solver stream and
+            // the step is ONE launch.  (An interior launch beside the exchange and a rim launch behind it, the two-pass
+            // step's scheme, costs this kernel more than it hides: it fills every CU's LDS and registers, the rim
+            // workgroups and the pack / unpack kernels next to it are starved -- 80 and 40-76 us instead of 25 and 6 --
+            // and every hand-over between the two hardware queues adds 30-80 us.)
+            rc = s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err) ? fail(PCL_ECOMM, err) : PCL_OK;
+            if (!rc) rc = do_step2ds(s, s->q, s->t2, dt);
+            s->vbc_on = 0;
+            if (rc) { s->ghosts_drop_all(); return bail(s, rc); }
+            std::swap(s->q, s->t2);
+            s->undo_slot = &s->t2;
+            return read_cfl(s, cfl);
+        }
         if (s->overlap == 2) {
             // test mode (PCL_HALO_OVERLAP=2): same launches on ONE stream with the interior tiles strictly
             // BEFORE the exchange -- an interior tile that read a ghost cell would see the stale frame

@@ -3,7 +3,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 def short(n):
-    for k, v in (('Euler5, 1', 'x-pass'), ('Euler5, 2', 'y-pass'), ('ncclDevKernel', 'nccl'), ('halo_pack', 'halo_pack'),
+    for k, v in (('step2ds', 'step2ds'), ('Euler5, 1', 'x-pass'), ('Euler5, 2', 'y-pass'), ('ncclDevKernel', 'nccl'), ('halo_pack', 'halo_pack'),
                  ('cfl_handover', 'cfl_handover'), ('fillBuffer', 'fill'), ('copyBuffer', 'copy'), ('frame_kernel', 'frame'),
                  ('unsplit_x', 'unsplit_x'), ('unsplit_y', 'unsplit_y'), ('sharp_kernel', 'sharp')):
         if k in n: return v
