@@ -8,9 +8,9 @@
 // Riemann solvers and mbc != 2.
 //
 // Tile: 32 rows x 64 columns of q with a 2-cell halo on every side, all MEQN planes in LDS (Euler: 80 KB, two
-// workgroups per CU).  Three phases, one barrier between them:
+// workgroups per CU).  Four phases, a barrier in front of the y sweeps and one behind them:
 //   load   the tile, ghost cells remapped to their boundary-condition source cells (tiles on the frame only);
-//   x      wavefront w sweeps rows w, w+8, w+16, w+24: one lane = one cell, the row is a 64-lane strip exactly as in
+//   x      wavefront w sweeps the four rows it loaded (2w, 2w+1, 16+2w, 17+2w): one lane = one cell, the row is a 64-lane strip exactly as in
 //          the x pass; the 60 inner lanes put the updated cell back IN PLACE (interior columns only: ghost columns
 //          are copied through, step2ds.f:141-146).  All 32 rows are swept: the y sweeps below need q* two rows beyond
 //          the rows they update;
@@ -36,6 +36,9 @@ constexpr int F_THREADS = 512, F_WAVES = F_THREADS / WAVE;
 #ifndef PCL_FUSED_NT      /* 1: the tile loads bypass the caches like the two-pass kernels' (A/B) */
 #define PCL_FUSED_NT 0
 #endif
+// rows of the tile wavefront w loads and sweeps, k = 0..3: 2w, 2w+1, 16+2w, 17+2w (what 512 threads taking the tile's
+// 16-byte pairs in order, 32 pairs per row, give it)
+__device__ __forceinline__ int wave_row(int w, int k) { return (k >> 1) * (F_ROWS / 2) + 2 * w + (k & 1); }
 __device__ __forceinline__ int ftile_at(int m, int r, int c) { return (m * F_ROWS + r) * F_COLS + (c ^ r); }
 
 template <class RP, bool FWAVE, bool SRC>
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
     static_assert(!SRC || MEQN == 5, "fused source: the Euler solver");
     __shared__ __attribute__((aligned(16))) double tile[MEQN * F_ROWS * F_COLS];
 
-    int bid = xcd_logical_block(a.xcd);
+    // (plain block order: the XCD-contiguous order of xcd_logical_block costs this kernel 3 %)
+    int bid = blockIdx.x;
     int tx = bid % ntx, ty = bid / ntx;
     if (a.sub != 0) {
         // decomposed block (pclaw.hip): the tiles inside box = [ty_lo, ty_hi) x [tx_lo, tx_hi) read no ghost cell a
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
     } else {
 #pragma unroll
         for (int k = 0; k < F_ROWS * F_COLS / F_THREADS; k++) {
-            const int slot = threadIdx.x + F_THREADS * k;
-            const int r = slot / F_COLS, c = slot % F_COLS;
+            // the rows this thread's WAVEFRONT sweeps (wave_row below): the same rows the 16-byte path gives it
+            const int r = wave_row(threadIdx.x / WAVE, k), c = threadIdx.x & (WAVE - 1);
             int gx = x0 + c, gy = y0 + r;
             gx = gx < a.I ? gx : a.I - 1;            // past the edge: repeat the last cell (never feeds a stored value)
             gy = gy < a.J ? gy : a.J - 1;
@@ -127,7 +131,10 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
             }
         }
     }
-    __syncthreads();
+    // no workgroup barrier here: a wavefront sweeps exactly the four rows it loaded (the LDS operations of one
+    // wavefront stay in order; the fence keeps the compiler from moving the reads of other lanes' writes up)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     double cflx = 0.0, cfly = 0.0;
@@ -138,8 +145,9 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
         const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.mx) && lane >= HALO && lane < WAVE - HALO;
         const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.mx) && lane >= 1;
 #pragma unroll 1
-        for (int r = wv; r < F_ROWS; r += F_WAVES) {
-            if (y0 + r >= a.J) break;                 // wave-uniform
+        for (int k = 0; k < F_ROWS / F_WAVES; k++) {
+            const int r = wave_row(wv, k);
+            if (y0 + r >= a.J) continue;              // wave-uniform
             double q[MEQN], qn[MEQN];
 #pragma unroll
             for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, r, lane)];
