@@ -532,6 +532,8 @@ def main():
         else:
             key = {("exact", "bubble"): "exact", ("exact", "dense"): "exact_dense", ("fast", "dense"): "fast_dense"}.get(
                 (args.math, args.state))
+            if not one_kernel and key == "exact":
+                key = "exact_twopass"           # PCL_TUNE_FUSED_STEP=0 / decomposed blocks without an interior box
             pm = (key, ["step2ds_kernel", "Euler5"] if one_kernel else ["sweep_kernel", "Euler5, %d," % (dom + 1)])
             dflt = size == 1 and key is not None and (args.nx, args.ny) == (4096, 4096)
         traffic, traffic_source = pmc_traffic(pm[0], pm[1], dflt)

@@ -3,7 +3,8 @@
 #   1. rocprofv3 --kernel-trace --stats of one bench command per kernel family, the bench JSON of the SAME run next to it;
 #   2. in SEPARATE passes --pmc FETCH_SIZE / --pmc WRITE_SIZE (MI355X_MICROARCH.md: KB units, FETCH_SIZE x2 on gfx950) of
 #      the same commands -> <tag>_pmc_hbm.json via tools/pmc_summary.py (bench.py reads roofline.traffic from it);
-#   3. SQ issue counters of the dense state, and SQ_LDS_BANK_CONFLICT of the y pass with the swizzled tile (the build)
+#   3. SQ issue counters of the dense state (one-kernel step; PCL_TUNE_FUSED_STEP=0: the two passes) and of the SharpClaw
+#      right-hand side, and SQ_LDS_BANK_CONFLICT of the y pass with the swizzled tile (the build)
 #      and with the padded round-1 tile (build/libs/libpyclaw_amd_ypad.so, -DPCL_YTILE_PAD=1).
 # Usage: tools/profile_r03.sh <tag> <commit>
 set -e
@@ -16,6 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 B="--no-cpu-baseline --no-states"
 declare -A CMD
 CMD[exact]="$R/bench.py $B --math exact"
+CMD[exact_twopass]="$R/bench.py $B --math exact"          # PCL_TUNE_FUSED_STEP=0: x pass + y pass (classic.hpp)
 CMD[exact_dense]="$R/bench.py $B --math exact --state dense"
 CMD[fast_dense]="$R/bench.py $B --math fast --state dense"
 CMD[unsplit]="$R/bench.py $B --unsplit"
@@ -24,8 +26,9 @@ CMD[3d_dimsplit]="$R/bench.py --ndim 3 --nx 512"
 CMD[3d_unsplit]="$R/bench.py --ndim 3 --unsplit --nx 256"
 CMD[sphere_classic]="$R/bench.py --app sphere"
 CMD[sphere_sharpclaw]="$R/bench.py --app sphere --solver sharpclaw"
-ORDER="exact exact_dense fast_dense unsplit sharpclaw 3d_dimsplit 3d_unsplit sphere_classic sphere_sharpclaw"
+ORDER="exact exact_twopass exact_dense fast_dense unsplit sharpclaw 3d_dimsplit 3d_unsplit sphere_classic sphere_sharpclaw"
 for name in $ORDER; do
+  export PCL_TUNE_FUSED_STEP=1; [ "$name" = exact_twopass ] && export PCL_TUNE_FUSED_STEP=0
   steps=20; [ "$name" = sharpclaw ] && steps=4; [ "$name" = 3d_dimsplit ] && steps=6; [ "$name" = 3d_unsplit ] && steps=6
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 ${CMD[$name]} --steps $steps --warmup 3 \
       > $OUT/summary/${TAG}_bench_$name.json 2> $OUT/stats_$name.err
@@ -33,20 +36,27 @@ for name in $ORDER; do
   echo "stats $name done"
 done
 for name in $ORDER; do
+  export PCL_TUNE_FUSED_STEP=1; [ "$name" = exact_twopass ] && export PCL_TUNE_FUSED_STEP=0
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${name}_$C -- python3 ${CMD[$name]} --steps 2 --warmup 1 > $OUT/pmc_${name}_$C.log 2>&1
   done
   echo "pmc $name done"
 done
+export PCL_TUNE_FUSED_STEP=1
 python3 $R/tools/pmc_summary.py $OUT > $OUT/pmc_modes.json
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
 SQB="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/sq_a -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_a.log 2>&1
 rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/sq_b -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_b.log 2>&1
 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/sq_fast_a -- python3 ${CMD[fast_dense]} --steps 3 --warmup 1 > $OUT/sq_fast_a.log 2>&1
+rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/sq_sharp_a -- python3 ${CMD[sharpclaw]} --steps 1 --warmup 1 > $OUT/sq_sharp_a.log 2>&1
+export PCL_TUNE_FUSED_STEP=0
+rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/sq_2p_a -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_2p_a.log 2>&1
+rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/sq_2p_b -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_2p_b.log 2>&1
 export PCL_LIB_OVERRIDE=$R/build/libs/libpyclaw_amd_ypad.so
-rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/sq_b_ypad -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_b_ypad.log 2>&1
+rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/sq_2p_b_ypad -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_2p_b_ypad.log 2>&1
 unset PCL_LIB_OVERRIDE
+export PCL_TUNE_FUSED_STEP=1
 echo "sq done"
 python3 - $OUT $TAG $COMMIT <<'PY'
 import csv, glob, json, sys, collections
@@ -59,15 +69,17 @@ res = {"commit": commit,
 json.dump(res, open("%s/summary/%s_pmc_hbm.json" % (out, tag), "w"), indent=1)
 with open("%s/summary/%s_pmc_sq.txt" % (out, tag), "w") as fo:
     fo.write("rocprofv3 --pmc <SQ counters> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-states "
-             "--state dense   (commit %s)\n  sq_a / sq_b: --math exact, two passes of 8 counters;  sq_fast_a: --math fast;\n"
-             "  sq_b_ypad: the sq_b counters with build/libs/libpyclaw_amd_ypad.so (-DPCL_YTILE_PAD=1: the y-pass tile padded to 17 "
+             "--state dense   (commit %s)\n  sq_a / sq_b: --math exact (the one-kernel step), two passes of 8 counters;  sq_fast_a: --math fast;\n"
+             "  sq_sharp_a: bench.py --solver sharpclaw (the SharpClaw right-hand side);\n"
+             "  sq_2p_a / sq_2p_b: PCL_TUNE_FUSED_STEP=0, the x pass + y pass form of the same step;\n"
+             "  sq_2p_b_ypad: the sq_2p_b counters with build/libs/libpyclaw_amd_ypad.so (-DPCL_YTILE_PAD=1: the y-pass tile padded to 17 "
              "doubles per row instead of XOR-swizzled) -- the before / after pair for SQ_LDS_BANK_CONFLICT\n" % commit)
-    for sub in ("sq_a", "sq_b", "sq_fast_a", "sq_b_ypad"):
+    for sub in ("sq_a", "sq_b", "sq_fast_a", "sq_sharp_a", "sq_2p_a", "sq_2p_b", "sq_2p_b_ypad"):
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
         for f in glob.glob(out + "/%s/**/*counter_collection.csv" % sub, recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
-                if "sweep_kernel" not in k: continue
+                if "sweep_kernel" not in k and "step2ds_kernel" not in k and "sharp_kernel" not in k: continue
                 k = k[:80]
                 acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 n[(k, r["Counter_Name"])] += 1
