@@ -325,6 +325,12 @@ int pcl_timer_stop(pcl_solver *s, float *ms);
  * launch duration and removes most of that). */
 int pcl_kernel_timing(pcl_solver *s, int enable);
 int pcl_kernel_timing_read(pcl_solver *s, double *ms_total, long *launches);
+/* The dimension-split 2-D step has two forms with identical results (step2ds.f:83-159 as x pass + y pass, or both sweeps
+ * in one kernel, q through HBM once per step); one block of an aux-free solver runs the faster one, re-measured every 256
+ * steps (PCL_TUNE_FUSED_STEP = 0 / 1 pins a form).  Since the last pcl_kernel_timing reset: cumulative device time (ms)
+ * and sampled launch count of the one-kernel step (pcl_kernel_timing_read holds the two passes), and the steps each
+ * form has run. */
+int pcl_step_form_stats(pcl_solver *s, double *ms_total, long *launches, long *steps_one_kernel, long *steps_two_pass);
 /* hyperbolic steps (classic) / right-hand sides (SharpClaw) attempted since pcl_create, rejected ones included */
 int pcl_step_count(pcl_solver *s, long *steps);
 

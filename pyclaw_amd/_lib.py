@@ -102,6 +102,7 @@ PROTOTYPES = {
     "pcl_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "pcl_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pcl_kernel_timing_read": (C.c_int, [C.c_void_p, dp, C.POINTER(C.c_long)]),
+    "pcl_step_form_stats": (C.c_int, [C.c_void_p, dp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "pcl_step_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "pcl_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pcl_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, ip]),

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <chrono>
 #include <string>
 #include <utility>
 #include <vector>
@@ -66,8 +67,17 @@ struct pcl_solver {
     struct Timed { hipEvent_t a, b; int which; bool count; };
     std::vector<Timed> timed;
     std::vector<hipEvent_t> evpool;
-    double kt_ms[2] = {0, 0};
-    long kt_n[2] = {0, 0};
+    double kt_ms[3] = {0, 0, 0};      // x pass / y pass (or phases) / the one-kernel dim-split step
+    long kt_n[3] = {0, 0, 0};
+    // Which form of the dimension-split 2-D step runs (identical results): PCL_TUNE_FUSED_STEP = 0 two passes, 1 one
+    // kernel, 2 (default) the faster of the two, measured: at the start of every window of FORM_WINDOW steps a few steps
+    // of each form are timed on the host (a step ends with the Courant number's read-back) and the rest of the window
+    // runs the faster one.  The one-kernel step halves the HBM traffic and wins wherever most wavefronts take the
+    // no-jump shortcut; where every cell is active its halo rows (32 / 28 of the arithmetic) make the two passes faster.
+    int form_now = 1;               // 1 = one kernel, 0 = two passes
+    long form_step = 0;             // steps since the window began
+    double form_t[2] = {0, 0};      // best (smallest) wall time of a trial step of each form in this window
+    long form_steps[2] = {0, 0};    // steps run in each form (pcl_step_form_stats)
     pcl::Halo halo;
     // halo exchange overlapped with the interior of the x pass (pcl_bc_step, dim-split 2-D)
     hipStream_t hstream = nullptr;
@@ -437,8 +447,12 @@ int do_sweep(pcl_solver *s, const double *qin, double *qout, int ids, double dt,
 // The dimension-split 2-D step as ONE kernel (classic_fused.hpp): two ghost layers, Riemann solvers without aux
 // arrays, no capacity function.  PCL_TUNE_FUSED_STEP=0 keeps the two passes.
 // sub/box: tile subset (interior / rim of a decomposed block), `on`: the halo stream for the rim launch.
+int fused_step_mode() {
+    static const int on = [] { const char *e = getenv("PCL_TUNE_FUSED_STEP"); return e ? atoi(e) : 2; }();
+    return on;
+}
 bool fused_step_ok(const pcl_solver *s) {
-    static const int on = [] { const char *e = getenv("PCL_TUNE_FUSED_STEP"); return e ? atoi(e) : 1; }();
+    const int on = fused_step_mode();
     const int rp = s->cfg.rp;
     return on && s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.mbc == 2 && s->cfg.method[5] <= 0 && s->cfg.meqn <= 5 &&
            (rp == PCL_RP_EULER5_2D || rp == PCL_RP_ACOUSTICS_2D || rp == PCL_RP_ADVECTION_2D || rp == PCL_RP_SHALLOW_2D);
@@ -456,7 +470,7 @@ int do_step2ds(pcl_solver *s, const double *qin, double *qout, double dt, int su
     if (timed) {
         t.a = get_event(s);
         t.b = get_event(s);
-        t.which = 0;
+        t.which = 2;
         t.count = sub != 2;
         hipEventRecord(t.a, stream);
     }
@@ -1118,7 +1132,23 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
         std::swap(s->q, s->t1);
         s->undo_slot = &s->t1;
     } else if (s->cfg.method[2] < 0) {  // dimensional splitting, clawpack.py:538-546
-        if (fused_step_ok(s)) {
+        // one block: the faster form of the step, re-measured every FORM_WINDOW steps (pcl_solver::form_now)
+        constexpr long FORM_WINDOW = 256;
+        constexpr int FORM_TRIAL = 3;       // timed steps per form at the start of a window (the first one untimed)
+        const bool can = fused_step_ok(s);
+        const bool tune = can && fused_step_mode() == 2 && !s->halo.active;
+        int form = can ? 1 : 0;
+        if (tune) {
+            const long k = s->form_step % FORM_WINDOW;
+            if (k == 0) s->form_t[0] = s->form_t[1] = 1e30;
+            if (k < 2 * (FORM_TRIAL + 1)) form = k < FORM_TRIAL + 1 ? 1 : 0;
+            else {
+                if (k == 2 * (FORM_TRIAL + 1)) s->form_now = s->form_t[0] < 0.98 * s->form_t[1] ? 0 : 1;
+                form = s->form_now;
+            }
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (form == 1) {
             if (int rc = do_step2ds(s, s->q, s->t2, dt)) return bail(s, rc);
         } else {
             if (int rc = do_sweep(s, s->q, s->t1, 1, dt)) return bail(s, rc);
@@ -1126,6 +1156,17 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
         }
         std::swap(s->q, s->t2);
         s->undo_slot = &s->t2;
+        s->form_steps[form]++;
+        const int rc = read_cfl(s, cfl);
+        if (tune) {
+            const long k = s->form_step % FORM_WINDOW;
+            if (k < 2 * (FORM_TRIAL + 1) && k % (FORM_TRIAL + 1) != 0) {      // a trial step, not the first of its form
+                const double dtw = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (dtw < s->form_t[form]) s->form_t[form] = dtw;
+            }
+            s->form_step++;
+        }
+        return rc;
     } else {  // unsplit, clawpack.py:550-552 -> step2.f
         if (int rc = do_unsplit(s, dt)) return bail(s, rc);
         std::swap(s->q, s->t1);
@@ -1241,6 +1282,7 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             if (!rc && he != hipSuccess) rc = fail(PCL_EHIP, std::string("halo stream join: ") + hipGetErrorString(he));
             s->vbc_on = 0;
             if (rc) { s->ghosts_drop_all(); return bail(s, rc); }
+            s->form_steps[1]++;
             std::swap(s->q, s->t2);
             s->undo_slot = &s->t2;
             s->ghosts_mark(s->q);
@@ -1256,6 +1298,7 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             if (!rc) rc = do_step2ds(s, s->q, s->t2, dt);
             s->vbc_on = 0;
             if (rc) { s->ghosts_drop_all(); return bail(s, rc); }
+            s->form_steps[1]++;
             std::swap(s->q, s->t2);
             s->undo_slot = &s->t2;
             return read_cfl(s, cfl);
@@ -1300,6 +1343,7 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             s->ghosts_drop(s->t2);                   // the y pass writes that buffer, ghost rows included
             if (int rc2 = do_sweep(s, s->t1, s->t2, 2, dt)) { s->ghosts_drop_all(); return bail(s, rc2); }
         }
+        s->form_steps[onek ? 1 : 0]++;
         std::swap(s->q, s->t2);
         s->undo_slot = &s->t2;
         if (s->exchange_ahead && s->overlap == 1) {
@@ -1647,8 +1691,9 @@ int pcl_kernel_timing(pcl_solver *s, int enable) {
     if (!s) return fail(PCL_EINVAL, "null argument");
     if (int rc = drain_timing(s)) return rc;
     s->timing = enable < 0 ? 0 : enable;
-    s->kt_ms[0] = s->kt_ms[1] = 0;
-    s->kt_n[0] = s->kt_n[1] = 0;
+    s->kt_ms[0] = s->kt_ms[1] = s->kt_ms[2] = 0;
+    s->kt_n[0] = s->kt_n[1] = s->kt_n[2] = 0;
+    s->form_steps[0] = s->form_steps[1] = 0;
     return PCL_OK;
 }
 int pcl_step_count(pcl_solver *s, long *steps) {
@@ -1661,6 +1706,16 @@ int pcl_kernel_timing_read(pcl_solver *s, double *ms_total, long *launches) {
     if (int rc = drain_timing(s)) return rc;
     ms_total[0] = s->kt_ms[0]; ms_total[1] = s->kt_ms[1];
     launches[0] = s->kt_n[0]; launches[1] = s->kt_n[1];
+    return PCL_OK;
+}
+
+int pcl_step_form_stats(pcl_solver *s, double *ms_total, long *launches, long *steps_one_kernel, long *steps_two_pass) {
+    if (!s || !ms_total || !launches || !steps_one_kernel || !steps_two_pass) return fail(PCL_EINVAL, "null argument");
+    if (int rc = drain_timing(s)) return rc;
+    *ms_total = s->kt_ms[2];
+    *launches = s->kt_n[2];
+    *steps_one_kernel = s->form_steps[1];
+    *steps_two_pass = s->form_steps[0];
     return PCL_OK;
 }
 
