@@ -588,6 +588,13 @@ def main():
                 "both passes of the step, so it is charged 160 B per cell.  The kernel itself moves q through HBM once "
                 "per step (80 B per cell + 8.8 B of halo re-reads): see traffic; against THAT count the launch reaches "
                 "%.0f GB/s (%.3f of the peak)" % (achieved * 88.8 / 160.0, achieved * 88.8 / 160.0 / HBM_PEAK_GBS))
+            # the same launch priced by what THIS form has to move: q in once, q out once per step
+            own = bytes_pass / (avg[0] * 1e-3) / 1e9 if avg[0] else 0.0
+            out["roofline"]["one_kernel_step"] = {
+                "min_bytes_per_launch": bytes_pass, "achieved": own, "unit": "GB/s", "frac": own / HBM_PEAK_GBS,
+                "note": "one read + one write of q per STEP (80 B per cell): the floor of the one-kernel form; "
+                        "roofline.achieved / frac above keep SURVEY 8(d)'s two-pass count so that they compare with "
+                        "the x pass + y pass form and with earlier rounds"}
             out["config"]["step_form"] = dict(forms, note="two forms of the dim-split step with identical results; the "
                                               "solver runs the faster one, re-measured every 256 steps (3 timed steps of each)")
         ceil, ceil_src = copy_ceiling()
