@@ -218,13 +218,49 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     using Cell = typename RP::Cell;
 
+    const double dtdx_l = CAPA ? from_left(dtdx_c) : dtdx_c;
+    double wave[MWAVES][MEQN], s[MWAVES], amdq[MEQN], apdq[MEQN];
+
+    // Solvers without aux arrays: the no-jump test (below) on the raw cell values, BEFORE the cell's derived quantities
+    // exist -- a jump-free wavefront then needs neither the shift of the whole Cell (12 doubles for Euler) nor the
+    // quantities only the full solve reads (the compiler drops them from this branch): equal q means the left cell's
+    // Cell equals this lane's bit for bit, so the Roe average is taken of (c, c).  Same speeds, same Courant number.
+    if constexpr (!FWAVE && RP::NAUX == 0) {
+        const bool lane0 = (threadIdx.x & (WAVE - 1)) == 0;   // lane 0 has no left cell
+        // (every shift runs with all lanes active, outside the short-circuit expressions: a DPP read of a lane that is
+        // masked off returns nothing useful)
+        const double ql0 = from_left(q[0]);
+        bool same = !(a.ablate & 16) && __all(lane0 || ql0 == q[0]);
+        if (same) {      // wave-uniform
+            double ql[MEQN];
+#pragma unroll
+            for (int m = 1; m < MEQN; m++) ql[m] = from_left(q[m]);
+            bool rest = true;
+#pragma unroll
+            for (int m = 1; m < MEQN; m++) rest = rest & (ql[m] == q[m]);
+            same = __all(lane0 || rest);
+        }
+        if (same) {
+            const Cell c = RP::template precell<IXY>(q, a.par);
+            RP::template speeds<IXY>(c, c, a.par, s);
+            bool finite = true;
+#pragma unroll
+            for (int mw = 0; mw < MWAVES; mw++) finite = finite && (s[mw] - s[mw] == 0.0);
+            if (__all(finite || lane0)) {
+                if (!(a.ablate & 8)) cfl_accumulate<CAPA, MWAVES>(s, dtdx_c, dtdx_l, cfl_ok, cflmax);
+#pragma unroll
+                for (int m = 0; m < MEQN; m++) {
+                    if constexpr (TRANS) { qn[m] = 0.0; df[m] = 0.0; g1[m] = 0.0; g2[m] = 0.0; }  // the slice's pieces
+                    else qn[m] = q[m];
+                }
+                return;
+            }
+        }
+    }
     Cell cR;
     if constexpr (RP::NAUX > 0) cR = RP::template precell<IXY>(q, a.par, auxv);
     else cR = RP::template precell<IXY>(q, a.par);
     const Cell cL = struct_from_left(cR);
-    const double dtdx_l = CAPA ? from_left(dtdx_c) : dtdx_c;
-
-    double wave[MWAVES][MEQN], s[MWAVES], amdq[MEQN], apdq[MEQN];
 
     // A wavefront without a single jump (every lane's cell equals its left neighbour: undisturbed gas,
     // the inside of the bubble, a constant post-shock state): all waves, fluctuations and correction
@@ -232,7 +268,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
     // that (q + 0).  Only the wave speeds are needed, for the Courant number (flux2.f:109-117); they come
     // from the same Roe average the full solve uses.  Wave-uniform branch; a non-finite speed (unphysical
     // state) takes the full path.  PCL_TUNE_ABLATE bit 4 switches the shortcut off (tools/kbench.py).
-    if constexpr (!FWAVE) {   // f-waves over varying aux are non-zero even for equal q: no shortcut there
+    if constexpr (!FWAVE && RP::NAUX > 0) {   // f-waves over varying aux are non-zero even for equal q: no shortcut there
         const bool lane0 = (threadIdx.x & (WAVE - 1)) == 0;   // lane 0 has no left cell
         // first component first: where the state varies at all, one compare per lane settles it
         bool same = !(a.ablate & 16) && __all(lane0 || cL.q[0] == cR.q[0]);
