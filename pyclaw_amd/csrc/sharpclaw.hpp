@@ -50,6 +50,25 @@ __device__ __forceinline__ void weno5_pyweno(double qm2, double qm1, double q0, 
                           ((c833 * qm1) * qm1) + ((c1033 * qm1) * q0) + ((c333 * q0) * q0);
     const double t0 = sigma0 + eps, t1 = sigma1 + eps, t2 = sigma2 + eps;
     const double d0 = t0 * t0, d1 = t1 * t1, d2 = t2 * t2;
+#if PCL_FAST
+    // fast mode (rtol 1e-12, not bit-identical): the weights w_k / d_k, normalised, are (w_k * prod_{j != k} d_j) / sum --
+    // two reciprocals instead of five and no quotient per weight; the candidates are combined BEFORE the one division.
+    // Range: d >= 1e-72 and sigma ~ q^2, so the pair products stay far inside the double range (|q| < 1e38).
+    {
+        const double d12 = d1 * d2, d02 = d0 * d2, d01 = d0 * d1;
+        const double a0 = w01 * d12, a1 = w06 * d02, a2 = w03 * d01;      // left weights  (0.1, 0.6, 0.3)
+        const double b0 = w03 * d12, b2 = w01 * d01;                      // right weights (0.3, 0.6, 0.1): b1 == a1
+        const double fr0 = f183 * q0 + f116 * qp1 + f033 * qp2;
+        const double fr1 = f033 * qm1 + f083 * q0 + f016 * qp1;
+        const double fr2 = f016 * qm2 + f083 * qm1 + f033 * q0;
+        const double fr3 = f033 * q0 + f083 * qp1 + f016 * qp2;
+        const double fr4 = f016 * qm1 + f083 * q0 + f033 * qp1;
+        const double fr5 = f033 * qm2 + f116 * qm1 + f183 * q0;
+        ql = (a0 * fr0 + a1 * fr1 + a2 * fr2) * Recip(a0 + a1 + a2).r;
+        qr = (b0 * fr3 + a1 * fr4 + b2 * fr5) * Recip(b0 + a1 + b2).r;
+        return;
+    }
+#endif
     // 12 divisions, 5 distinct denominators (each (sigma+eps)^2 >= 1e-72 is used twice, each weight
     // sum three times): shared-reciprocal quotients, the same correctly rounded values (rp.hpp).
     const Recip by_d0(d0), by_d1(d1), by_d2(d2);
