@@ -517,8 +517,11 @@ __device__ __forceinline__ int xcd_logical_block(int on) {
 
 // SRC: the instantiation that applies the fused source term while storing (y pass of the Euler solver only; the
 // plain instantiation keeps its store loops untouched: a run-time switch there cost the memory-bound pass 4-5 %)
+#ifndef PCL_SWEEP_OCC      /* workgroups per CU the aux-free instantiations are register-allocated for (A/B: 1 = no target) */
+#define PCL_SWEEP_OCC 4
+#endif
 template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool SRC = false>
-__global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
+__global__ __launch_bounds__(256, (RP::NAUX == 0 && !CAPA) ? PCL_SWEEP_OCC : 1) void sweep_kernel(SweepArgs a, int ntiles_across, int ntiles_along) {
     using T = TileShape<IXY>;
     constexpr int MEQN = RP::MEQN;
     // tile planes: q(0..MEQN-1), the capacity function (CAPA), then the first RP::NAUX aux components for

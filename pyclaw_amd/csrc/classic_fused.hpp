@@ -48,8 +48,9 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
     static_assert(!SRC || MEQN == 5, "fused source: the Euler solver");
     __shared__ __attribute__((aligned(16))) double tile[MEQN * F_ROWS * F_COLS];
 
-    // (plain block order: the XCD-contiguous order of xcd_logical_block costs this kernel 3 %)
-    int bid = blockIdx.x;
+    // (plain block order: the XCD-contiguous order of xcd_logical_block costs this kernel 3 % although it saves HBM
+    // reads -- PCL_TUNE_XCD bit 1 switches it on for A/B)
+    int bid = (a.xcd & 2) ? xcd_logical_block(1) : (int)blockIdx.x;
     int tx = bid % ntx, ty = bid / ntx;
     if (a.sub != 0) {
         // decomposed block (pclaw.hip): the tiles inside box = [ty_lo, ty_hi) x [tx_lo, tx_hi) read no ghost cell a
