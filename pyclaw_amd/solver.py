@@ -126,6 +126,14 @@ class Solver(object):
         pass
 
     def teardown(self):
+        # bookkeeping that dies with the handle: how many steps ran in each form of the dimension-split 2-D step
+        # (one kernel / two passes; identical results, the library runs the faster one -- pcl_step_form_stats)
+        if self._h is not None and hasattr(self, "status"):
+            import ctypes
+            ms, n, s1, s0 = ctypes.c_double(), ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
+            if _lib.lib().pcl_step_form_stats(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(s1),
+                                              ctypes.byref(s0)) == 0:
+                self.status["step_forms"] = {"one_kernel": int(s1.value), "two_pass": int(s0.value)}
         self._release()
 
     def _release(self):

@@ -18,9 +18,16 @@ import pyclaw_amd as pyclaw                     # noqa: E402
 from apps import problems                       # noqa: E402
 import mp_fullsize_worker as W                  # noqa: E402
 
+LAST_FORMS = None
+
 
 def finish(claw):
     st = claw.solution.state
+    global LAST_FORMS
+    claw.solver.teardown()          # (a second call is harmless) leaves status["step_forms"]
+    f = claw.solver.status.get("step_forms")
+    if f is not None:
+        LAST_FORMS = [f["one_kernel"], f["two_pass"]]
     out = {"hash": W.block_hash(st.q), "steps": int(claw.solver.status["numsteps"]),
            "cflmax": repr(float(claw.solver.status["cflmax"])), "dt": repr(float(claw.solver.dt)),
            "finite": bool(np.isfinite(st.q).all())}
@@ -85,6 +92,9 @@ def main():
             ("thin_300x5", (300, 5), [per, per, out, out], [4, 4, 4, 4, 2], 2, False),
             ("narrow_3x90", (3, 90), [ref, ref, per, per], [4, 4, 4, 4, 2], 2, False)):
         res[tag] = synthetic_euler(mx, my, bc, lim, order, src)
+    # 45 steps: in the default mode (PCL_TUNE_FUSED_STEP=2) the solver's trial steps (16..23 of a window) run both forms
+    res["window_200x90"] = synthetic_euler(200, 90, [per, per, out, ref], [4, 4, 4, 4, 2], 2, True, steps=45)
+    forms = LAST_FORMS
     # the other aux-free 2-D solvers
     claw = problems.acoustics2D(pyclaw, mx=130, my=75, tfinal=0.05, nout=1, dim_split=1, run=False)
     claw.keep_copy = False
@@ -93,6 +103,7 @@ def main():
     res["acoustics_130x75"] = finish(claw)
     claw = problems.radial_dam_break(pyclaw, n=150, tfinal=0.1, dim_split=True)
     res["dam_break_150"] = finish(claw) if hasattr(claw, "solver") else {"hash": W.block_hash(np.asarray(claw))}
+    sys.stderr.write("forms %s\n" % json.dumps(forms))      # not part of the compared line
     print(json.dumps(res))
 
 

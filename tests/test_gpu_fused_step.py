@@ -27,14 +27,20 @@ def run_worker(fused):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fused_step_worker.py")], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    return json.loads(p.stdout.strip().splitlines()[-1])
+    forms = [json.loads(l[6:]) for l in p.stderr.splitlines() if l.startswith("forms ")]
+    return json.loads(p.stdout.strip().splitlines()[-1]), (forms[-1] if forms else None)
 
 
 def test_one_kernel_step_equals_two_passes():
-    one, two = run_worker(1), run_worker(0)
-    assert set(one) == set(two) and len(one) >= 14
+    (one, f1), (two, f0), (auto, fa) = run_worker(1), run_worker(0), run_worker(2)
+    assert set(one) == set(two) == set(auto) and len(one) >= 15
     for k in sorted(one):
         assert one[k].get("finite", True), k
         assert one[k] == two[k], (k, one[k], two[k])
+        assert one[k] == auto[k], (k, one[k], auto[k])
+    # the pinned runs used one form only; the default mode ran its trial steps in both (45-step case: [steps in the
+    # one-kernel form, steps in the two-pass form] from pcl_step_form_stats)
+    assert f1[1] == 0 and f1[0] >= 45 and f0[0] == 0 and f0[1] >= 45, (f1, f0)
+    assert fa[0] >= 4 and fa[1] >= 4 and fa[0] + fa[1] == f1[0], fa
     # the runs did something: the app rejected its first step and went on
     assert one["shockbubble_160x40"]["steps"] >= 3
