@@ -70,7 +70,7 @@ struct pcl_solver {
     double kt_ms[3] = {0, 0, 0};      // x pass / y pass (or phases) / the one-kernel dim-split step
     long kt_n[3] = {0, 0, 0};
     // Which form of the dimension-split 2-D step runs (identical results): PCL_TUNE_FUSED_STEP = 0 two passes, 1 one
-    // kernel, 2 (default) the faster of the two, measured: 16 steps into every window of FORM_WINDOW steps a few steps
+    // kernel, 2 (default) the faster of the two, measured: 64 steps into every window of FORM_WINDOW steps a few steps
     // of each form are timed on the host (a step ends with the Courant number's read-back) and the rest of the window
     // runs the faster one.  The one-kernel step halves the HBM traffic and wins wherever most wavefronts take the
     // no-jump shortcut; where every cell is active its halo rows (32 / 28 of the arithmetic) make the two passes faster.
@@ -1138,7 +1138,7 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
         const bool can = fused_step_ok(s);
         const bool tune = can && fused_step_mode() == 2 && !s->halo.active;
         int form = can ? 1 : 0;
-        constexpr long FORM_T0 = 16;        // the trials start 16 steps into a window: a short run never meets them
+        constexpr long FORM_T0 = 64;        // the trials start 64 steps into a window: a short run never meets them
         if (tune) {
             const long k = s->form_step % FORM_WINDOW - FORM_T0;
             if (k == 0) s->form_t[0] = s->form_t[1] = 1e30;

@@ -92,8 +92,8 @@ def main():
             ("thin_300x5", (300, 5), [per, per, out, out], [4, 4, 4, 4, 2], 2, False),
             ("narrow_3x90", (3, 90), [ref, ref, per, per], [4, 4, 4, 4, 2], 2, False)):
         res[tag] = synthetic_euler(mx, my, bc, lim, order, src)
-    # 45 steps: in the default mode (PCL_TUNE_FUSED_STEP=2) the solver's trial steps (16..23 of a window) run both forms
-    res["window_200x90"] = synthetic_euler(200, 90, [per, per, out, ref], [4, 4, 4, 4, 2], 2, True, steps=45)
+    # 80 steps: in the default mode (PCL_TUNE_FUSED_STEP=2) the solver's trial steps (64..71 of a window) run both forms
+    res["window_200x90"] = synthetic_euler(200, 90, [per, per, out, ref], [4, 4, 4, 4, 2], 2, True, steps=80)
     forms = LAST_FORMS
     # the other aux-free 2-D solvers
     claw = problems.acoustics2D(pyclaw, mx=130, my=75, tfinal=0.05, nout=1, dim_split=1, run=False)

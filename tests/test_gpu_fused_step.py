@@ -38,9 +38,9 @@ def test_one_kernel_step_equals_two_passes():
         assert one[k].get("finite", True), k
         assert one[k] == two[k], (k, one[k], two[k])
         assert one[k] == auto[k], (k, one[k], auto[k])
-    # the pinned runs used one form only; the default mode ran its trial steps in both (45-step case: [steps in the
+    # the pinned runs used one form only; the default mode ran its trial steps in both (80-step case: [steps in the
     # one-kernel form, steps in the two-pass form] from pcl_step_form_stats)
-    assert f1[1] == 0 and f1[0] >= 45 and f0[0] == 0 and f0[1] >= 45, (f1, f0)
+    assert f1[1] == 0 and f1[0] >= 80 and f0[0] == 0 and f0[1] >= 80, (f1, f0)
     assert fa[0] >= 4 and fa[1] >= 4 and fa[0] + fa[1] == f1[0], fa
     # the runs did something: the app rejected its first step and went on
     assert one["shockbubble_160x40"]["steps"] >= 3
