@@ -351,7 +351,11 @@ int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128],
  * still filled).  petclaw has no counterpart (globalToLocal is blocking, petclaw/state.py:254-262).  EVERY rank of
  * the communicator must make the same choice (the order of operations on the communicator depends on it):
  * pcl_halo_can_overlap tells whether this rank's block qualifies (decomposed, dim-split 2-D, interior x-pass tiles,
- * PCL_HALO_OVERLAP=1); the caller agrees over all ranks (pyclaw_amd/clawpack.py) and then switches it on everywhere. */
+ * PCL_HALO_OVERLAP=1); the caller agrees over all ranks (pyclaw_amd/clawpack.py) and then switches it on everywhere.
+ * pcl_halo_can_overlap: 0 no, 1 yes, 2 yes and the block can also run the one-kernel form of the step (both sweeps in
+ * one launch) with interior / rim tile subsets.  That form sends the new state's halo behind its RIM tiles, beside the
+ * interior launch and BEFORE the Courant number's all-reduce: on = 2 selects that order and is only valid when every
+ * rank reported 2; on = 1 keeps the two-pass order (all-reduce, then the exchange) on every rank. */
 int pcl_halo_can_overlap(pcl_solver *s, int *yes);
 int pcl_halo_exchange_ahead(pcl_solver *s, int on);
 /* The same decomposed device path with a host-staged wire instead of RCCL (diagnostics, and multi-process tests on

@@ -262,8 +262,11 @@ class ClawSolver(Solver):
         mine = (bool(yes.value) and os.environ.get("PCL_EXCHANGE_AHEAD", "1") != "0"
                 and not self._pre_step_modifies_q() and (self.step_src is None or self._src_fused)
                 and self._device_bc_spec(state) is not None and not state.grid.gauges)
-        if all(parallel.allgather(bool(mine))):
-            _lib.check(_lib.lib().pcl_halo_exchange_ahead(self._h, 1))
+        # 2: the block also has an interior box of one-kernel tiles.  The one-kernel step sends the new halo behind its
+        # rim tiles, BEFORE the Courant number's all-reduce; the two-pass step after it: one order for the whole run
+        codes = parallel.allgather(int(yes.value) if mine else 0)
+        if all(c > 0 for c in codes):
+            _lib.check(_lib.lib().pcl_halo_exchange_ahead(self._h, 2 if all(c == 2 for c in codes) else 1))
             self.exchange_ahead = True
 
     def _decide_src_fusion(self, state):

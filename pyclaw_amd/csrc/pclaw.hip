@@ -1201,6 +1201,9 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
     // 4-row tiles for the overlap
     bool onek = fused_step_ok(s), overlapped = false;
     if (s->halo.active && fused && s->cfg.ndim == 2 && s->overlap && s->sel == 0) {
+        // (exchange-ahead in the two-pass order, agreed by the ranks because some block is too thin for one-kernel tiles:
+        // this rank keeps that order too)
+        if (s->exchange_ahead == 1) onek = false;
         if (onek && pcl::exact::step2ds_interior_box(make_args(s, s->q, s->t2, 1, dt), box, ntiles)) overlapped = true;
         else {
             onek = false;
@@ -2060,9 +2063,12 @@ int pcl_comm_init_host(pcl_solver *s, int nranks, int rank, const int neighbors[
 int pcl_halo_can_overlap(pcl_solver *s, int *yes) {
     if (!s || !yes) return fail(PCL_EINVAL, "null argument");
     int box[4], ntiles[2];
-    *yes = s->halo.active && s->cfg.kind == PCL_KIND_CLASSIC && s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.meqn <= 8 &&
-           s->overlap == 1 && ((fused_step_ok(s) && pcl::exact::step2ds_interior_box(make_args(s, s->q, s->t2, 1, 1.0), box, ntiles)) ||
-                               pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, 1.0), box, ntiles));
+    const bool base = s->halo.active && s->cfg.kind == PCL_KIND_CLASSIC && s->cfg.ndim == 2 && s->cfg.method[2] < 0 &&
+                      s->cfg.meqn <= 8 && s->overlap == 1;
+    // 2: this block can also run the one-kernel step with interior / rim tile subsets; 1: the two-pass step only
+    *yes = !base ? 0
+           : (fused_step_ok(s) && pcl::exact::step2ds_interior_box(make_args(s, s->q, s->t2, 1, 1.0), box, ntiles)) ? 2
+           : pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, 1.0), box, ntiles) ? 1 : 0;
     return PCL_OK;
 }
 
@@ -2073,9 +2079,13 @@ int pcl_halo_exchange_ahead(pcl_solver *s, int on) {
         if (int rc = pcl_halo_can_overlap(s, &yes)) return rc;
         if (!yes) return fail(PCL_ESTATE, "pcl_halo_exchange_ahead: needs the overlapped dimension-split 2-D step of a decomposed run "
                                           "(pcl_comm_init done, PCL_HALO_OVERLAP=1, a block with interior x-pass tiles)");
+        if (on == 2 && yes != 2)
+            return fail(PCL_ESTATE, "pcl_halo_exchange_ahead(2): this block has no interior box of one-kernel tiles (pcl_halo_can_overlap < 2)");
         if (!s->ev_y) HIP_TRY(hipEventCreateWithFlags(&s->ev_y, hipEventDisableTiming));
     }
-    s->exchange_ahead = on ? 1 : 0;
+    // 1: the two-pass step's order on the communicator (all-reduce, then the new state's exchange); 2: the one-kernel
+    // step's (the exchange behind the rim tiles, then the all-reduce).  Every rank of a run must hold the same value.
+    s->exchange_ahead = on == 2 ? 2 : on ? 1 : 0;
     s->ghosts_drop_all();
     return PCL_OK;
 }

@@ -171,8 +171,8 @@ def test_overlapped_step_equals_periodic(mx, my, overlap, monkeypatch):
     assert not np.array_equal(res[0][0], q0)
 
 
-@pytest.mark.parametrize("mx,my", [(1000, 37), (723, 9), (4096, 2048)])
-def test_exchange_ahead_equals_periodic_with_retake(mx, my, monkeypatch):
+@pytest.mark.parametrize("mx,my,order", [(1000, 37, 0), (723, 9, 0), (4096, 2048, 0), (4096, 2048, 1), (1024, 300, 1)])
+def test_exchange_ahead_equals_periodic_with_retake(mx, my, order, monkeypatch):
     """pcl_halo_exchange_ahead: the halo of the new state is exchanged behind the y pass that produced it and the next
     step skips its own exchange.  A sequence with everything that can come between two steps -- accepted steps, a
     rejected one (pcl_undo_step: back to the pre-step buffer and its still-filled ghost frame), a retake with a smaller
@@ -200,8 +200,10 @@ def test_exchange_ahead_equals_periodic_with_retake(mx, my, monkeypatch):
                 L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
                 yes = C.c_int(0)
                 L.check(lib.pcl_halo_can_overlap(h, C.byref(yes)))
-                assert yes.value == 1
-                L.check(lib.pcl_halo_exchange_ahead(h, 1))
+                assert yes.value in (1, 2)       # 2: the one-kernel step with tile subsets (its own exchange-ahead order)
+                # order 0: what the block offers; 1: the two-pass order although the block could run the one-kernel step
+                # (what a run does when another rank's block is too thin for one-kernel tiles)
+                L.check(lib.pcl_halo_exchange_ahead(h, 1 if order else yes.value))
                 bc = np.full(4, -1, dtype=np.int32)
             else:
                 bc = np.full(4, 2, dtype=np.int32)

@@ -37,7 +37,9 @@ def run(mx, my, steps, comm, overlap, ahead=False, state="uniform"):
         L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
         bc = np.full(4, -1, dtype=np.int32)
         if ahead:
-            L.check(lib.pcl_halo_exchange_ahead(h, 1))
+            yes = C.c_int(0)
+            L.check(lib.pcl_halo_can_overlap(h, C.byref(yes)))
+            L.check(lib.pcl_halo_exchange_ahead(h, yes.value))       # 2: the one-kernel step's order (rim tiles first)
     else:
         bc = np.full(4, 2, dtype=np.int32)
     rng = np.random.default_rng(0)
