@@ -29,20 +29,45 @@
 namespace pcl {
 namespace PCL_NS {
 
-constexpr int F_ROWS = 32, F_COLS = WAVE;
+// Tile shape (build-time A/B: -DPCL_FUSED_ROWS / _COLS / _THREADS).  32 x 64 with 512 threads is two 80 KB workgroups
+// per CU for Euler; 32 x 32 and 16 x 64 with 256 threads are four of 40 KB (shorter phases, more of them in flight,
+// for 7 % / 17 % more halo work).
+#ifndef PCL_FUSED_ROWS
+#define PCL_FUSED_ROWS 32
+#endif
+#ifndef PCL_FUSED_COLS
+#define PCL_FUSED_COLS 64
+#endif
+#ifndef PCL_FUSED_THREADS
+#define PCL_FUSED_THREADS 512
+#endif
+constexpr int F_ROWS = PCL_FUSED_ROWS, F_COLS = PCL_FUSED_COLS;
 constexpr int F_OWN_R = F_ROWS - 2 * HALO, F_OWN_C = F_COLS - 2 * HALO;
-constexpr int F_THREADS = 512, F_WAVES = F_THREADS / WAVE;
+constexpr int F_THREADS = PCL_FUSED_THREADS, F_WAVES = F_THREADS / WAVE;
+constexpr int F_RX = WAVE / F_COLS;          // rows of the tile one wavefront sweeps at a time (x sweeps)
+constexpr int F_CY = WAVE / F_ROWS;          // columns one wavefront sweeps at a time (y sweeps)
+constexpr int F_PPR = F_COLS / 2;            // 16-byte pairs per tile row
+constexpr int F_NK = F_ROWS * F_PPR / F_THREADS;        // 16-byte loads per thread and plane
+constexpr int F_SPK = (WAVE / F_PPR) / F_RX;            // x sweeps that cover the rows of one such load
+constexpr int F_NS = F_NK * F_SPK;                      // x sweeps per wavefront
+static_assert(F_COLS * F_RX == WAVE && F_ROWS * F_CY == WAVE && F_OWN_C % 2 == 0, "tile shape");
+static_assert(F_ROWS * F_PPR % F_THREADS == 0 && (WAVE / F_PPR) % F_RX == 0, "tile shape");
+static_assert(F_NS * F_RX * F_WAVES == F_ROWS && (F_COLS / F_CY) % F_WAVES == 0, "tile shape");
 
 #ifndef PCL_FUSED_NT      /* 1: the tile loads bypass the caches like the two-pass kernels' (A/B) */
 #define PCL_FUSED_NT 0
 #endif
-// rows of the tile wavefront w loads and sweeps, k = 0..3: 2w, 2w+1, 16+2w, 17+2w (what 512 threads taking the tile's
-// 16-byte pairs in order, 32 pairs per row, give it)
-__device__ __forceinline__ int wave_row(int w, int k) { return (k >> 1) * (F_ROWS / 2) + 2 * w + (k & 1); }
-__device__ __forceinline__ int ftile_at(int m, int r, int c) { return (m * F_ROWS + r) * F_COLS + (c ^ r); }
+// first row of the tile wavefront w loads and sweeps in its x sweep k = 0..F_NS-1 (32 x 64, 512 threads: 2w, 2w+1,
+// 16+2w, 17+2w -- what the threads taking the tile's 16-byte pairs in order give it); lanes >= F_COLS take the next row
+__device__ __forceinline__ int wave_row(int w, int k) {
+    return (F_THREADS * (k / F_SPK) + WAVE * w) / F_PPR + (k % F_SPK) * F_RX;
+}
+// column swizzle of row r: a half-wave of the y sweeps (32 / F_ROWS columns x F_ROWS rows) must hit 32 distinct banks
+__device__ __forceinline__ int fswz(int r) { return F_ROWS >= 32 ? r : r * (32 / F_ROWS); }
+__device__ __forceinline__ int ftile_at(int m, int r, int c) { return (m * F_ROWS + r) * F_COLS + (c ^ fswz(r)); }
 
 template <class RP, bool FWAVE, bool SRC>
-__global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kernel(SweepArgs a, int ntx, int nty) {
+__global__ __launch_bounds__(F_THREADS, F_THREADS == 512 ? (RP::MEQN > 3 ? 2 : 3) : 1024 / F_THREADS) void step2ds_kernel(SweepArgs a, int ntx, int nty) {
     constexpr int MEQN = RP::MEQN;
     static_assert(RP::NAUX == 0, "solvers without aux arrays");
     static_assert(!SRC || MEQN == 5, "fused source: the Euler solver");
@@ -51,6 +76,13 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
     // (plain block order: the XCD-contiguous order of xcd_logical_block costs this kernel 3 % although it saves HBM
     // reads -- PCL_TUNE_XCD bit 1 switches it on for A/B)
     int bid = (a.xcd & 2) ? xcd_logical_block(1) : (int)blockIdx.x;
+    if (a.xcd & 4) {
+        // chunked order (A/B, PCL_TUNE_XCD bit 2): the hardware deals consecutive workgroups to the 8 XCDs in turn; in
+        // every window of 64 tiles each XCD takes 8 CONSECUTIVE tiles of a tile row (they share partial lines and halo
+        // columns in that XCD's L2) while the windows still walk the grid in row order
+        const int nb = gridDim.x, win = bid >> 6;
+        if ((win + 1) << 6 <= nb) bid = (win << 6) + ((bid & 7) << 3) + ((bid >> 3) & 7);
+    }
     int tx = bid % ntx, ty = bid / ntx;
     if (a.sub != 0) {
         // decomposed block (pclaw.hip): the tiles inside box = [ty_lo, ty_hi) x [tx_lo, tx_hi) read no ghost cell a
@@ -97,15 +129,15 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
 #else
                 double2 v = *reinterpret_cast<const double2 *>(&a.qin[m * a.plane + g]);
 #endif
-                if (r & 1) { const double t = v.x; v.x = v.y; v.y = t; }       // the swizzle swaps the pair in odd rows
-                *reinterpret_cast<double2 *>(&tile[(m * F_ROWS + r) * F_COLS + ((c ^ r) & ~1)]) = v;
+                if (fswz(r) & 1) { const double t = v.x; v.x = v.y; v.y = t; }       // the swizzle swaps the pair in odd rows
+                *reinterpret_cast<double2 *>(&tile[(m * F_ROWS + r) * F_COLS + ((c ^ fswz(r)) & ~1)]) = v;
             }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < F_ROWS * F_COLS / F_THREADS; k++) {
             // the rows this thread's WAVEFRONT sweeps (wave_row below): the same rows the 16-byte path gives it
-            const int r = wave_row(threadIdx.x / WAVE, k), c = threadIdx.x & (WAVE - 1);
+            const int r = wave_row(threadIdx.x / WAVE, k) + (threadIdx.x & (WAVE - 1)) / F_COLS, c = threadIdx.x & (F_COLS - 1);
             int gx = x0 + c, gy = y0 + r;
             gx = gx < a.I ? gx : a.I - 1;            // past the edge: repeat the last cell (never feeds a stored value)
             gy = gy < a.J ? gy : a.J - 1;
@@ -142,24 +174,25 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
 
     // ---- x sweeps of the tile's rows (step2ds.f:83-146) --------------------------------------------------------
     {
-        const int ca = x0 + lane;
-        const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.mx) && lane >= HALO && lane < WAVE - HALO;
-        const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.mx) && lane >= 1;
+        const int cl = lane & (F_COLS - 1);           // (F_RX rows per wavefront where the tile is narrower than it)
+        const int ca = x0 + cl;
+        const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.mx) && cl >= HALO && cl < F_COLS - HALO;
+        const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.mx) && cl >= 1;
 #pragma unroll 1
-        for (int k = 0; k < F_ROWS / F_WAVES; k++) {
-            const int r = wave_row(wv, k);
-            if (y0 + r >= a.J) continue;              // wave-uniform
+        for (int k = 0; k < F_NS; k++) {
+            const int r0 = wave_row(wv, k), r = r0 + lane / F_COLS;
+            if (y0 + r0 >= a.J) continue;             // wave-uniform
             double q[MEQN], qn[MEQN];
 #pragma unroll
-            for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, r, lane)];
+            for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, r, cl)];
             if (a.ablate & 1) {      // diagnostic (tools/kbench.py): the kernel's memory traffic without its arithmetic
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) qn[m] = q[m];
             } else
-                lane_core<RP, 1, false, FWAVE, false>(q, a.dtd, 1.0, cfl_ok, a, qn, cflx);
+                lane_core<RP, 1, false, FWAVE, false>(q, a.dtd, 1.0, cfl_ok && (F_RX == 1 || y0 + r < a.J), a, qn, cflx);
             if (owned) {
 #pragma unroll
-                for (int m = 0; m < MEQN; m++) tile[ftile_at(m, r, lane)] = qn[m];
+                for (int m = 0; m < MEQN; m++) tile[ftile_at(m, r, cl)] = qn[m];
             }
         }
     }
@@ -174,15 +207,18 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
         const bool row_owned = (gy >= a.mbc) && (gy < a.mbc + a.my) && rl >= HALO && rl < F_ROWS - HALO;
         const bool row_cfl = (gy >= a.mbc) && (gy <= a.mbc + a.my) && rl >= 1;
 #pragma unroll 1
-        for (int p = wv; p < F_COLS / 2; p += F_WAVES) {
-            const int c = 2 * p + h, gx = x0 + c;
+        for (int p = wv; p < F_COLS / F_CY; p += F_WAVES) {
+            const int c = F_CY * p + h, gx = x0 + c;
             // columns that hold q*: the tile's own interior columns and every ghost column (copied through by the x
             // sweeps; step2ds sweeps them too and their wave speeds count for the Courant number)
             auto has_qstar = [&](int cc) {
                 const int g = x0 + cc;
                 return g < a.I && ((cc >= HALO && cc < F_COLS - HALO) || g < a.mbc || g >= a.mbc + a.mx);
             };
-            if (!has_qstar(2 * p) && !has_qstar(2 * p + 1)) continue;      // wave-uniform
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < F_CY; j++) any = any || has_qstar(F_CY * p + j);
+            if (!any) continue;                                            // wave-uniform
             const bool col_ok = has_qstar(c);
             const bool col_int = c >= HALO && c < F_COLS - HALO && gx >= a.mbc && gx < a.mbc + a.mx;
             double q[MEQN], qn[MEQN];
@@ -215,8 +251,8 @@ __global__ __launch_bounds__(F_THREADS, RP::MEQN > 3 ? 2 : 3) void step2ds_kerne
                 double2 v[MEQN];
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) {
-                    v[m] = *reinterpret_cast<const double2 *>(&tile[(m * F_ROWS + r) * F_COLS + ((c ^ r) & ~1)]);
-                    if (r & 1) { const double t = v[m].x; v[m].x = v[m].y; v[m].y = t; }
+                    v[m] = *reinterpret_cast<const double2 *>(&tile[(m * F_ROWS + r) * F_COLS + ((c ^ fswz(r)) & ~1)]);
+                    if (fswz(r) & 1) { const double t = v[m].x; v[m].x = v[m].y; v[m].y = t; }
                 }
                 if constexpr (SRC) {
                     const double2 rad = *reinterpret_cast<const double2 *>(&a.aux[g]);
