@@ -195,6 +195,21 @@ template <bool CAPA> __device__ __forceinline__ double cfl_value(double cflmax, 
     return CAPA ? cflmax : dtd * cflmax;
 }
 
+// The last undisturbed state a wavefront met and its largest |wave speed| (one-kernel step, classic_fused.hpp).  In a
+// wavefront without a jump every lane holds the SAME cell, so the key is wave-uniform: it lives in scalar registers
+// (v_readlane), the test is MEQN compares against scalar operands, and a hit skips precell + speeds (two square
+// roots, a handful of quotients) -- in undisturbed gas strip after strip has the same state.  Same bits: equal q gives
+// equal speeds (+0 == -0 compares equal and cannot change a |speed|).
+template <int MEQN> struct NoJumpMemo {
+    double key[MEQN];
+    double m;
+    int valid = 0;
+};
+__device__ __forceinline__ double uniform_from_lane1(double x) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 1), hi = __builtin_amdgcn_readlane(__double2hiint(x), 1);
+    return __hiloint2double(hi, lo);
+}
+
 // ---- the per-lane core ------------------------------------------------------------------
 // q      : this lane's cell
 // dtdx_c : dtdx1d of this lane's cell (dt/dx, divided by capa when present)
@@ -209,12 +224,13 @@ template <bool CAPA> __device__ __forceinline__ double cfl_value(double cflmax, 
 // (fadd = cqxx), the update is associated like the 2-D one ((q + qadd) - dtdx*(fadd(i+1)-fadd(i))).
 // auxv: this cell's aux values for Riemann solvers with RP::NAUX > 0.
 template <class RP, int IXY, bool CAPA, bool FWAVE, bool DIM1, bool TRANS = false, bool F3 = false>
-__device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dtdx_c, double capa,
+__device__ __forceinline__ bool lane_core(const double (&q)[RP::MEQN], double dtdx_c, double capa,
                                           bool cfl_ok, const SweepArgs &a,
                                           double (&qn)[RP::MEQN], double &cflmax,
                                           double *df = nullptr, double *g1 = nullptr, double *g2 = nullptr,
                                           const double *auxv = nullptr, const double *auxb = nullptr,
-                                          const double *auxa = nullptr, const double *auxo = nullptr) {
+                                          const double *auxa = nullptr, const double *auxo = nullptr,
+                                          NoJumpMemo<RP::MEQN> *memo = nullptr) {   // returns: the no-jump shortcut was taken (wave-uniform)
     constexpr int MEQN = RP::MEQN, MWAVES = RP::MWAVES;
     using Cell = typename RP::Cell;
 
@@ -241,6 +257,19 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
             same = __all(lane0 || rest);
         }
         if (same) {
+            if constexpr (!CAPA && !TRANS) {
+                if (memo && memo->valid) {       // wave-uniform: the state of the last jump-free strip again?
+                    bool hit = true;
+#pragma unroll
+                    for (int m = 0; m < MEQN; m++) hit = hit & (q[m] == memo->key[m]);
+                    if (__all(hit)) {
+                        if (!(a.ablate & 8) && cfl_ok) cflmax = dmax(cflmax, memo->m);
+#pragma unroll
+                        for (int m = 0; m < MEQN; m++) qn[m] = q[m];
+                        return true;
+                    }
+                }
+            }
             const Cell c = RP::template precell<IXY>(q, a.par);
             RP::template speeds<IXY>(c, c, a.par, s);
             bool finite = true;
@@ -248,12 +277,23 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
             for (int mw = 0; mw < MWAVES; mw++) finite = finite && (s[mw] - s[mw] == 0.0);
             if (__all(finite || lane0)) {
                 if (!(a.ablate & 8)) cfl_accumulate<CAPA, MWAVES>(s, dtdx_c, dtdx_l, cfl_ok, cflmax);
+                if constexpr (!CAPA && !TRANS) {
+                    if (memo) {                  // every lane holds this cell: lane 1's copy is the wavefront's
+                        double mx = fabs(s[0]);
+#pragma unroll
+                        for (int mw = 1; mw < MWAVES; mw++) mx = dmax(mx, fabs(s[mw]));
+                        memo->m = uniform_from_lane1(mx);
+#pragma unroll
+                        for (int m = 0; m < MEQN; m++) memo->key[m] = uniform_from_lane1(q[m]);
+                        memo->valid = 1;
+                    }
+                }
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) {
                     if constexpr (TRANS) { qn[m] = 0.0; df[m] = 0.0; g1[m] = 0.0; g2[m] = 0.0; }  // the slice's pieces
                     else qn[m] = q[m];
                 }
-                return;
+                return true;
             }
         }
     }
@@ -290,7 +330,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                     if constexpr (TRANS) { qn[m] = 0.0; df[m] = 0.0; g1[m] = 0.0; g2[m] = 0.0; }  // the slice's pieces
                     else qn[m] = q[m];
                 }
-                return;
+                return true;
             }
         }
     }
@@ -415,7 +455,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                 g2[m] = g2[m] - 0.5 * dtdx_c * bp[m];
             }
         }
-        return;
+        return false;
     }
 
     // update, step2ds.f:141-157 / step1.f:93-96,136-138
@@ -436,6 +476,7 @@ __device__ __forceinline__ void lane_core(const double (&q)[RP::MEQN], double dt
                 qn[m] = q[m] + qadd - a.dtd * (fadd_r - fadd[m]);
         }
     }
+    return false;
 }
 
 // ---- the sweep kernel: tiles staged through LDS ------------------------------------------------

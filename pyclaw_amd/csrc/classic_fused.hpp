@@ -7,21 +7,23 @@
 // as the two-pass form (classic.hpp), which stays the path for decomposed blocks, capacity functions, aux-carrying
 // Riemann solvers and mbc != 2.
 //
-// Tile: 32 rows x 64 columns of q with a 2-cell halo on every side, all MEQN planes in LDS (Euler: 80 KB, two
-// workgroups per CU).  Four phases, a barrier in front of the y sweeps and one behind them:
+// Tile: 16 rows x 64 columns of q with a 2-cell halo on every side, all MEQN planes in LDS (Euler: 40 KB, four
+// workgroups of 256 threads per CU; the round's first form was 32 x 64 with 512 threads, two per CU -- still a build
+// option, see PCL_FUSED_ROWS below).  Four phases, a barrier in front of the y sweeps and one behind them:
 //   load   the tile, ghost cells remapped to their boundary-condition source cells (tiles on the frame only);
-//   x      wavefront w sweeps the four rows it loaded (2w, 2w+1, 16+2w, 17+2w): one lane = one cell, the row is a 64-lane strip exactly as in
-//          the x pass; the 60 inner lanes put the updated cell back IN PLACE (interior columns only: ghost columns
-//          are copied through, step2ds.f:141-146).  All 32 rows are swept: the y sweeps below need q* two rows beyond
-//          the rows they update;
-//   y      a wavefront takes TWO columns at a time, 32 rows each (lanes 0..31 / 32..63 = the rows of column c / c+1;
-//          the wavefront shifts between lanes 31 and 32 only feed halo rows): rows 2..29 of the interior columns put
-//          the finished cell back in place;
-//   store  rows 2..29 x columns 2..61 (interior cells only), 16 bytes per lane.
-// HBM traffic per cell and step: (32*64)/(28*60) reads + 1 write of q = 88.8 B for Euler instead of 2 x 82.5 B.
-// The halo rows / columns are computed twice (x phase 32/28, y phase 32/28 lanes): +14 % arithmetic, which the
-// wave-uniform no-jump shortcut of lane_core makes cheap wherever the gas is undisturbed.
-// LDS layout: row-major rows of 64 doubles, the column XOR-swizzled with the row: the x phase (lanes = columns)
+//   x      wavefront w sweeps the four rows it loaded (2w, 2w+1, 8+2w, 9+2w): one lane = one cell, the row is a 64-lane
+//          strip exactly as in the x pass; the 60 inner lanes put the updated cell back IN PLACE (interior columns only:
+//          ghost columns are copied through, step2ds.f:141-146).  All 16 rows are swept: the y sweeps below need q* two
+//          rows beyond the rows they update;
+//   y      a wavefront takes FOUR columns at a time, 16 rows each (lanes 16h .. 16h+15 = the rows of column c+h; the
+//          wavefront shifts across those boundaries only feed halo rows): rows 2..13 of the interior columns put the
+//          finished cell back in place;
+//   store  rows 2..13 x columns 2..61 (interior cells only), 16 bytes per lane.
+// HBM traffic per cell and step: (16*64)/(12*60) reads + 1 write of q = 96.9 B for Euler (32 x 64: 88.8 B) instead of
+// 2 x 82.5 B.  The halo rows / columns are computed twice (x phase 16/12 of the rows, y phase 16/12 of the lanes), which
+// the wave-uniform no-jump shortcut of lane_core makes cheap wherever the gas is undisturbed -- and there a wavefront
+// remembers the last undisturbed state it met (NoJumpMemo, classic.hpp): the same state again costs MEQN compares.
+// LDS layout: row-major rows of 64 doubles, the column XOR-swizzled with the row (fswz): the x phase (lanes = columns)
 // touches 64 consecutive doubles, the y phase (lanes = rows) 32 distinct 8-byte banks per half-wave.
 #pragma once
 #include "classic.hpp"
@@ -29,17 +31,19 @@
 namespace pcl {
 namespace PCL_NS {
 
-// Tile shape (build-time A/B: -DPCL_FUSED_ROWS / _COLS / _THREADS).  32 x 64 with 512 threads is two 80 KB workgroups
-// per CU for Euler; 32 x 32 and 16 x 64 with 256 threads are four of 40 KB (shorter phases, more of them in flight,
-// for 7 % / 17 % more halo work).
+// Tile shape (build-time A/B: -DPCL_FUSED_ROWS / _COLS / _THREADS; tools/fused_ab.sh).  32 x 64 with 512 threads is two
+// 80 KB workgroups per CU for Euler; 16 x 64 and 32 x 32 with 256 threads are four of 40 KB (shorter phases, more of them
+// in flight, for 17 % / 7 % more halo work).  Same box, 4096^2 shock-bubble state, ms per step: 32 x 64 0.350, 16 x 64
+// 0.331, 32 x 32 0.370 (its 256-byte row pieces stream badly: 0.376 even without arithmetic); dense state 0.835 / 0.94 /
+// 0.86 -- there the solver runs the two passes anyway (pclaw.hip, form trials).
 #ifndef PCL_FUSED_ROWS
-#define PCL_FUSED_ROWS 32
+#define PCL_FUSED_ROWS 16
 #endif
 #ifndef PCL_FUSED_COLS
 #define PCL_FUSED_COLS 64
 #endif
 #ifndef PCL_FUSED_THREADS
-#define PCL_FUSED_THREADS 512
+#define PCL_FUSED_THREADS 256
 #endif
 constexpr int F_ROWS = PCL_FUSED_ROWS, F_COLS = PCL_FUSED_COLS;
 constexpr int F_OWN_R = F_ROWS - 2 * HALO, F_OWN_C = F_COLS - 2 * HALO;
@@ -57,8 +61,8 @@ static_assert(F_NS * F_RX * F_WAVES == F_ROWS && (F_COLS / F_CY) % F_WAVES == 0,
 #ifndef PCL_FUSED_NT      /* 1: the tile loads bypass the caches like the two-pass kernels' (A/B) */
 #define PCL_FUSED_NT 0
 #endif
-// first row of the tile wavefront w loads and sweeps in its x sweep k = 0..F_NS-1 (32 x 64, 512 threads: 2w, 2w+1,
-// 16+2w, 17+2w -- what the threads taking the tile's 16-byte pairs in order give it); lanes >= F_COLS take the next row
+// first row of the tile wavefront w loads and sweeps in its x sweep k = 0..F_NS-1 (16 x 64, 256 threads: 2w, 2w+1,
+// 8+2w, 9+2w -- what the threads taking the tile's 16-byte pairs in order give it); lanes >= F_COLS take the next row
 __device__ __forceinline__ int wave_row(int w, int k) {
     return (F_THREADS * (k / F_SPK) + WAVE * w) / F_PPR + (k % F_SPK) * F_RX;
 }
@@ -73,17 +77,33 @@ __global__ __launch_bounds__(F_THREADS, F_THREADS == 512 ? (RP::MEQN > 3 ? 2 : 3
     static_assert(!SRC || MEQN == 5, "fused source: the Euler solver");
     __shared__ __attribute__((aligned(16))) double tile[MEQN * F_ROWS * F_COLS];
 
-    // (plain block order: the XCD-contiguous order of xcd_logical_block costs this kernel 3 % although it saves HBM
-    // reads -- PCL_TUNE_XCD bit 1 switches it on for A/B)
+    // (the XCD-contiguous order of xcd_logical_block costs this kernel 2-3 % although it saves HBM reads -- PCL_TUNE_XCD
+    // bit 1 switches it on for A/B)
     int bid = (a.xcd & 2) ? xcd_logical_block(1) : (int)blockIdx.x;
     if (a.xcd & 4) {
-        // chunked order (A/B, PCL_TUNE_XCD bit 2): the hardware deals consecutive workgroups to the 8 XCDs in turn; in
-        // every window of 64 tiles each XCD takes 8 CONSECUTIVE tiles of a tile row (they share partial lines and halo
-        // columns in that XCD's L2) while the windows still walk the grid in row order
+        // chunked order (the default; PCL_TUNE_XCD bit 2): the hardware deals consecutive workgroups to the 8 XCDs in
+        // turn; in every window of 64 tiles each XCD takes 8 CONSECUTIVE tiles of a tile row (they share partial lines
+        // and halo columns in that XCD's L2) while the windows still walk the grid in row order: without arithmetic
+        // 0.288 -> 0.274 ms, the shock-bubble step 0.331 -> 0.330 (16 x 64, before the memo)
         const int nb = gridDim.x, win = bid >> 6;
         if ((win + 1) << 6 <= nb) bid = (win << 6) + ((bid & 7) << 3) + ((bid >> 3) & 7);
     }
     int tx = bid % ntx, ty = bid / ntx;
+    if ((a.xcd & 8) && a.sub == 0 && ntx >= 8) {
+        // column bands (A/B only, PCL_TUNE_XCD bit 3; measured 25 % SLOWER on the shock-bubble state, equal without
+        // arithmetic): XCD x walks the tiles of column band x row by row, so a tile's
+        // neighbours to the left, right, above and below run on the same XCD (halo rows / columns and shared partial
+        // lines hit its L2) while all eight XCDs advance through the tile rows together.  The contiguous ranges of
+        // xcd_logical_block over the band-major order of the tiles: a bijection for any grid (bands differ by one column)
+        int l = xcd_logical_block(1);
+        const int wlo = ntx >> 3, nwide = ntx & 7;       // bands 0..nwide-1 have wlo + 1 columns
+        const int wide = nwide * (wlo + 1) * nty;
+        int b, w, r;
+        if (l < wide) { w = wlo + 1; b = l / (w * nty); r = l - b * w * nty; tx = b * w; }
+        else { l -= wide; w = wlo; b = l / (w * nty); r = l - b * w * nty; tx = nwide * (wlo + 1) + b * w; }
+        ty = r / w;
+        tx += r - ty * w;
+    }
     if (a.sub != 0) {
         // decomposed block (pclaw.hip): the tiles inside box = [ty_lo, ty_hi) x [tx_lo, tx_hi) read no ghost cell a
         // neighbour block has to send -- sub 1 = those (they run beside the halo exchange), 2 = the others
@@ -178,6 +198,7 @@ __global__ __launch_bounds__(F_THREADS, F_THREADS == 512 ? (RP::MEQN > 3 ? 2 : 3
         const int ca = x0 + cl;
         const bool owned = (ca >= a.mbc) && (ca < a.mbc + a.mx) && cl >= HALO && cl < F_COLS - HALO;
         const bool cfl_ok = (ca >= a.mbc) && (ca <= a.mbc + a.mx) && cl >= 1;
+        NoJumpMemo<MEQN> memo;
 #pragma unroll 1
         for (int k = 0; k < F_NS; k++) {
             const int r0 = wave_row(wv, k), r = r0 + lane / F_COLS;
@@ -185,12 +206,14 @@ __global__ __launch_bounds__(F_THREADS, F_THREADS == 512 ? (RP::MEQN > 3 ? 2 : 3
             double q[MEQN], qn[MEQN];
 #pragma unroll
             for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, r, cl)];
+            bool nojump = false;     // wave-uniform: the cells go back as they came, nothing to put back
             if (a.ablate & 1) {      // diagnostic (tools/kbench.py): the kernel's memory traffic without its arithmetic
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) qn[m] = q[m];
             } else
-                lane_core<RP, 1, false, FWAVE, false>(q, a.dtd, 1.0, cfl_ok && (F_RX == 1 || y0 + r < a.J), a, qn, cflx);
-            if (owned) {
+                nojump = lane_core<RP, 1, false, FWAVE, false>(q, a.dtd, 1.0, cfl_ok && (F_RX == 1 || y0 + r < a.J), a, qn, cflx,
+                                                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &memo);
+            if (owned && !nojump) {
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) tile[ftile_at(m, r, cl)] = qn[m];
             }
@@ -206,6 +229,7 @@ __global__ __launch_bounds__(F_THREADS, F_THREADS == 512 ? (RP::MEQN > 3 ? 2 : 3
         const int gy = y0 + rl;
         const bool row_owned = (gy >= a.mbc) && (gy < a.mbc + a.my) && rl >= HALO && rl < F_ROWS - HALO;
         const bool row_cfl = (gy >= a.mbc) && (gy <= a.mbc + a.my) && rl >= 1;
+        NoJumpMemo<MEQN> memo;
 #pragma unroll 1
         for (int p = wv; p < F_COLS / F_CY; p += F_WAVES) {
             const int c = F_CY * p + h, gx = x0 + c;
@@ -224,12 +248,14 @@ __global__ __launch_bounds__(F_THREADS, F_THREADS == 512 ? (RP::MEQN > 3 ? 2 : 3
             double q[MEQN], qn[MEQN];
 #pragma unroll
             for (int m = 0; m < MEQN; m++) q[m] = tile[ftile_at(m, rl, c)];
+            bool nojump = false;
             if (a.ablate & 1) {
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) qn[m] = q[m];
             } else
-                lane_core<RP, 2, false, FWAVE, false>(q, ay.dtd, 1.0, row_cfl && col_ok, ay, qn, cfly);
-            if (row_owned && col_int) {
+                nojump = lane_core<RP, 2, false, FWAVE, false>(q, ay.dtd, 1.0, row_cfl && col_ok, ay, qn, cfly,
+                                                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &memo);
+            if (row_owned && col_int && !nojump) {
 #pragma unroll
                 for (int m = 0; m < MEQN; m++) tile[ftile_at(m, rl, c)] = qn[m];
             }

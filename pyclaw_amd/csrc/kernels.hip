@@ -258,12 +258,12 @@ int launch_unsplit3(const Unsplit3Launch &l, std::string &err) {
 }
 
 #if !PCL_FAST
-// the same for the one-kernel step (classic_fused.hpp): tile (ty, tx) reads rows mbc-2+28*ty .. +31 and columns
+// the same for the one-kernel step (classic_fused.hpp): tile (ty, tx) reads rows mbc-2+F_OWN_R*ty .. +F_ROWS-1 and columns
 // mbc-2+60*tx .. +63; box = [ty_lo, ty_hi) x [tx_lo, tx_hi), ntiles = (nty, ntx)
 bool step2ds_interior_box(const SweepArgs &a, int box[4], int ntiles[2]) {
     const int ntx = (a.mx + F_OWN_C - 1) / F_OWN_C, nty = (a.my + F_OWN_R - 1) / F_OWN_R;
     box[0] = 1;
-    const int roomy = a.my + HALO - F_ROWS;       // 28*ty + 32 <= my + 2
+    const int roomy = a.my + HALO - F_ROWS;       // F_OWN_R*ty + F_ROWS <= my + 2
     box[1] = roomy < 0 ? 0 : std::min(nty, roomy / F_OWN_R + 1);
     box[2] = 1;
     const int roomx = a.mx + HALO - F_COLS;

@@ -290,7 +290,7 @@ SweepArgs make_args(pcl_solver *s, const double *qin, double *qout, int ids, dou
     for (int k = 0; k < 4; k++) { a.vbc[k] = s->vbc[k]; for (int m = 0; m < 8; m++) a.vconst[k][m] = s->vconst[k][m]; }
     static const int ablate = [] { const char *e = getenv("PCL_TUNE_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
-    static const int xcd = [] { const char *e = getenv("PCL_TUNE_XCD"); return e ? atoi(e) : 1; }();
+    static const int xcd = [] { const char *e = getenv("PCL_TUNE_XCD"); return e ? atoi(e) : 5; }();
     a.xcd = xcd;
     return a;
 }

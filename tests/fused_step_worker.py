@@ -74,18 +74,21 @@ def main():
     B = pyclaw.BC
     res = {}
     # the app itself: inflow / reflecting / outflow sides, adaptive dt incl. a rejected step, fused source
-    for (mx, my) in ((160, 40), (333, 61), (64, 28), (61, 29), (1030, 250)):
+    for (mx, my) in ((160, 40), (333, 61), (64, 28), (61, 29), (60, 12), (61, 13), (1030, 250)):
         claw = problems.shockbubble(pyclaw, mx=mx, my=my, tfinal=0.02, device_callbacks=True, run=False)
         claw.keep_copy = False
         claw.output_format = None
         claw.run()
         res["shockbubble_%dx%d" % (mx, my)] = finish(claw)
-    # every built-in boundary condition on every side, tile-edge sizes (60 / 28 owned cells per tile), first order,
-    # other limiters, no source
+    # every built-in boundary condition on every side, tile-edge sizes (60 owned columns, 12 owned rows per tile -- and
+    # the 28 rows of the 32-row tile shape), first order, other limiters, no source
     per, out, ref = B.periodic, B.outflow, B.reflecting
     for tag, (mx, my), bc, lim, order, src in (
             ("periodic_120x56", (120, 56), [per, per, per, per], [4, 4, 4, 4, 2], 2, True),
             ("periodic_121x57", (121, 57), [per, per, per, per], [4, 4, 4, 4, 2], 2, False),
+            ("periodic_120x24", (120, 24), [per, per, per, per], [4, 4, 4, 4, 2], 2, True),
+            ("periodic_121x25", (121, 25), [per, per, per, per], [4, 4, 4, 4, 2], 2, False),
+            ("mixed_59x11", (59, 11), [ref, out, out, ref], [4, 4, 4, 4, 2], 2, True),
             ("mixed_59x27", (59, 27), [out, ref, ref, out], [1, 2, 3, 4, 0], 2, True),
             ("mixed_200x90", (200, 90), [ref, out, per, per], [3, 3, 3, 3, 3], 2, False),
             ("order1_77x33", (77, 33), [out, out, ref, ref], [4, 4, 4, 4, 2], 1, True),

@@ -1,11 +1,11 @@
 """
 GPU: the two forms of the dimension-split 2-D step (step2ds.f) agree bit for bit.
-  PCL_TUNE_FUSED_STEP=1 (default)  both sweeps of a step in ONE kernel (classic_fused.hpp: 32 x 64 tile, x sweeps, y
+  PCL_TUNE_FUSED_STEP=1 (default)  both sweeps of a step in ONE kernel (classic_fused.hpp: 16 x 64 tile, x sweeps, y
                                    sweeps of the x-swept tile in LDS, q through HBM once per step)
   PCL_TUNE_FUSED_STEP=0            x pass + y pass (classic.hpp), the form decomposed blocks / capa / aux solvers use
 Every other GPU parity test runs the default; this one keeps the two-pass form of the same problems under test and pins
 the one-kernel step to it: the shock-bubble app (inflow / reflecting / outflow sides, adaptive dt with a rejected step,
-fused source), every built-in boundary condition, grids at and around the tile sizes (60 x 28 owned cells), thin and
+fused source), every built-in boundary condition, grids at and around the tile sizes (60 x 12 owned cells; 60 x 28 of the 32-row shape), thin and
 narrow grids, order 1, all limiters, acoustics and shallow water.  The switch is read once per process, hence the
 worker (tests/fused_step_worker.py).
 """
