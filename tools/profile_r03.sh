@@ -29,14 +29,6 @@ CMD[sphere_sharpclaw]="$R/bench.py --app sphere --solver sharpclaw"
 ORDER="exact exact_twopass exact_dense fast_dense unsplit sharpclaw 3d_dimsplit 3d_unsplit sphere_classic sphere_sharpclaw"
 for name in $ORDER; do
   export PCL_TUNE_FUSED_STEP=1; [ "$name" = exact_twopass ] && export PCL_TUNE_FUSED_STEP=0
-  steps=20; [ "$name" = sharpclaw ] && steps=4; [ "$name" = 3d_dimsplit ] && steps=6; [ "$name" = 3d_unsplit ] && steps=6
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 ${CMD[$name]} --steps $steps --warmup 3 \
-      > $OUT/summary/${TAG}_bench_$name.json 2> $OUT/stats_$name.err
-  cp $(find $OUT/stats_$name -name "*kernel_stats.csv" | head -1) $OUT/summary/${TAG}_kernel_stats_$name.csv
-  echo "stats $name done"
-done
-for name in $ORDER; do
-  export PCL_TUNE_FUSED_STEP=1; [ "$name" = exact_twopass ] && export PCL_TUNE_FUSED_STEP=0
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${name}_$C -- python3 ${CMD[$name]} --steps 2 --warmup 1 > $OUT/pmc_${name}_$C.log 2>&1
   done
@@ -44,6 +36,27 @@ for name in $ORDER; do
 done
 export PCL_TUNE_FUSED_STEP=1
 python3 $R/tools/pmc_summary.py $OUT > $OUT/pmc_modes.json
+# the HBM summary goes into the box's copy of profiles/ BEFORE the kernel-stats passes, so that the bench lines of those
+# passes carry roofline.traffic of THIS build (bench.py reads profiles/<tag>_pmc_hbm.json)
+python3 - $OUT $TAG $COMMIT $R <<'PY'
+import json, sys
+out, tag, commit, root = sys.argv[1:5]
+modes = json.load(open(out + "/pmc_modes.json"))
+res = {"commit": commit,
+       "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py <the command of the mode> --steps 2 --warmup 1",
+       "correction": "MI355X_MICROARCH.md HBM section: counters are in KB; on gfx950 FETCH_SIZE reads 1/2 of streamed bytes -> x2; WRITE_SIZE exact",
+       "modes": modes}
+for dst in ("%s/summary/%s_pmc_hbm.json" % (out, tag), "%s/profiles/%s_pmc_hbm.json" % (root, tag)):
+    json.dump(res, open(dst, "w"), indent=1)
+PY
+for name in $ORDER; do
+  export PCL_TUNE_FUSED_STEP=1; [ "$name" = exact_twopass ] && export PCL_TUNE_FUSED_STEP=0
+  steps=20; [ "$name" = sharpclaw ] && steps=4; [ "$name" = 3d_dimsplit ] && steps=6; [ "$name" = 3d_unsplit ] && steps=6
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 ${CMD[$name]} --steps $steps --warmup 3 \
+      > $OUT/summary/${TAG}_bench_$name.json 2> $OUT/stats_$name.err
+  cp $(find $OUT/stats_$name -name "*kernel_stats.csv" | head -1) $OUT/summary/${TAG}_kernel_stats_$name.csv
+  echo "stats $name done"
+done
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
 SQB="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/sq_a -- python3 ${CMD[exact_dense]} --steps 3 --warmup 1 > $OUT/sq_a.log 2>&1
@@ -61,12 +74,6 @@ echo "sq done"
 python3 - $OUT $TAG $COMMIT <<'PY'
 import csv, glob, json, sys, collections
 out, tag, commit = sys.argv[1], sys.argv[2], sys.argv[3]
-modes = json.load(open(out + "/pmc_modes.json"))
-res = {"commit": commit,
-       "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py <the command of the mode> --steps 2 --warmup 1",
-       "correction": "MI355X_MICROARCH.md HBM section: counters are in KB; on gfx950 FETCH_SIZE reads 1/2 of streamed bytes -> x2; WRITE_SIZE exact",
-       "modes": modes}
-json.dump(res, open("%s/summary/%s_pmc_hbm.json" % (out, tag), "w"), indent=1)
 with open("%s/summary/%s_pmc_sq.txt" % (out, tag), "w") as fo:
     fo.write("rocprofv3 --pmc <SQ counters> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-states "
              "--state dense   (commit %s)\n  sq_a / sq_b: --math exact (the one-kernel step), two passes of 8 counters;  sq_fast_a: --math fast;\n"
