@@ -35,14 +35,26 @@ def finish(claw):
     return out
 
 
-def synthetic_euler(mx, my, bc, limiters, order=2, src=True, steps=4):
+def patchwork(mx, my):
+    """constant patches (37 x 9 cells, three states, momenta that are +0 in one patch and -0 in the next): wavefronts
+    without a jump that meet the same state again, another undisturbed state, or the same state up to the sign of a
+    zero -- what the remembered-state shortcut of the one-kernel step (NoJumpMemo, classic.hpp) has to get right --
+    next to patch edges, where the full solve runs"""
+    states = np.array([[1.0, 0.0, 0.0, 2.5, 0.0], [1.0, -0.0, -0.0, 2.5, 0.0], [0.5, 0.3, -0.1, 1.7, 1.0],
+                       [1.0, 0.0, -0.0, 2.5, 0.0], [2.0, -0.4, 0.2, 6.0, 0.25]])
+    i, j = np.meshgrid(np.arange(mx), np.arange(my), indexing='ij')
+    k = ((i // 37) * 3 + (j // 9) * 2 + (i // 74)) % len(states)
+    return np.moveaxis(states[k], -1, 0).copy()
+
+
+def synthetic_euler(mx, my, bc, limiters, order=2, src=True, steps=4, init=None):
     """the dense synthetic state of the full-size tests on an mx x my grid with the given boundary conditions"""
     x = pyclaw.Dimension('x', 0.0, 2.0, mx)
     y = pyclaw.Dimension('y', 0.0, 2.0 * my / mx, my)
     state = pyclaw.State(pyclaw.Grid([x, y]), 5, 1)
     state.aux_global['gamma'] = W.GAMMA
     state.aux_global['gamma1'] = W.GAMMA1
-    state.q[...] = W.synth_euler(np.arange(mx), np.arange(my))
+    state.q[...] = W.synth_euler(np.arange(mx), np.arange(my)) if init is None else init(mx, my)
     problems.sb_auxinit(state)
     solver = pyclaw.ClawSolver2D()
     solver.rp = pyclaw.riemann.rp_euler_5wave_2d
@@ -95,6 +107,9 @@ def main():
             ("thin_300x5", (300, 5), [per, per, out, out], [4, 4, 4, 4, 2], 2, False),
             ("narrow_3x90", (3, 90), [ref, ref, per, per], [4, 4, 4, 4, 2], 2, False)):
         res[tag] = synthetic_euler(mx, my, bc, lim, order, src)
+    # constant patches: the remembered undisturbed state of the one-kernel step (hits, misses, +0 / -0)
+    res["patchwork_300x100"] = synthetic_euler(300, 100, [per, per, out, ref], [4, 4, 4, 4, 2], 2, False, steps=6, init=patchwork)
+    res["patchwork_src_190x61"] = synthetic_euler(190, 61, [out, ref, per, per], [4, 4, 4, 4, 2], 2, True, steps=3, init=patchwork)
     # 80 steps: in the default mode (PCL_TUNE_FUSED_STEP=2) the solver's trial steps (64..71 of a window) run both forms
     res["window_200x90"] = synthetic_euler(200, 90, [per, per, out, ref], [4, 4, 4, 4, 2], 2, True, steps=80)
     forms = LAST_FORMS
