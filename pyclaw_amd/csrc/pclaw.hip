@@ -74,6 +74,7 @@ struct pcl_solver {
     // of each form are timed on the host (a step ends with the Courant number's read-back) and the rest of the window
     // runs the faster one.  The one-kernel step halves the HBM traffic and wins wherever most wavefronts take the
     // no-jump shortcut; where every cell is active its halo rows (32 / 28 of the arithmetic) make the two passes faster.
+    int form_seq_tune = 0;          // set by pcl_bc_step around the sequential decomposed step: the trials run there too
     int form_now = 1;               // 1 = one kernel, 0 = two passes
     long form_step = 0;             // steps since the window began
     double form_t[2] = {0, 0};      // best (smallest) wall time of a trial step of each form in this window
@@ -1136,7 +1137,9 @@ int pcl_step_hyperbolic(pcl_solver *s, double dt, double *cfl) {
         constexpr long FORM_WINDOW = 256;
         constexpr int FORM_TRIAL = 3;       // timed steps per form at the start of a window (the first one untimed)
         const bool can = fused_step_ok(s);
-        const bool tune = can && fused_step_mode() == 2 && !s->halo.active;
+        // (a decomposed block whose exchange runs in front of the step, pcl_bc_step: every rank picks for itself -- both
+        // forms see the same ghost frame, give the same bits and leave the order on the communicator alone)
+        const bool tune = can && fused_step_mode() == 2 && (!s->halo.active || s->form_seq_tune);
         int form = can ? 1 : 0;
         constexpr long FORM_T0 = 64;        // the trials start 64 steps into a window: a short run never meets them
         if (tune) {
@@ -1298,14 +1301,16 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
             // step's scheme, costs this kernel more than it hides: it fills every CU's LDS and registers, the rim
             // workgroups and the pack / unpack kernels next to it are starved -- 80 and 40-76 us instead of 25 and 6 --
             // and every hand-over between the two hardware queues adds 30-80 us.)
+            // Behind the exchange the block steps like a single one: ONE launch or, where every cell is active, the x
+            // pass + y pass -- the faster form, re-measured every 256 steps by this rank for itself (pcl_step_hyperbolic;
+            // 4096^2 block, dense state: one kernel 1.01 ms, two passes 0.86).
             rc = s->halo.exchange(s->q, s->cfg.meqn, s->pitch, s->plane, err) ? fail(PCL_ECOMM, err) : PCL_OK;
-            if (!rc) rc = do_step2ds(s, s->q, s->t2, dt);
+            if (rc) { s->vbc_on = 0; s->ghosts_drop_all(); return bail(s, rc); }
+            s->form_seq_tune = 1;
+            rc = pcl_step_hyperbolic(s, dt, cfl);       // swaps the buffers, reads the (all-reduced) Courant number
+            s->form_seq_tune = 0;
             s->vbc_on = 0;
-            if (rc) { s->ghosts_drop_all(); return bail(s, rc); }
-            s->form_steps[1]++;
-            std::swap(s->q, s->t2);
-            s->undo_slot = &s->t2;
-            return read_cfl(s, cfl);
+            return rc;
         }
         if (s->overlap == 2) {
             // test mode (PCL_HALO_OVERLAP=2): same launches on ONE stream with the interior tiles strictly

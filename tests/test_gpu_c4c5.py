@@ -42,7 +42,7 @@ def free_port():
     return p
 
 
-def launch(case, nranks, expect_path, overlap=None, timeout=900):
+def launch(case, nranks, expect_path, overlap=None, timeout=900, ahead=None):
     port = free_port()
     procs = []
     for r in range(nranks):
@@ -52,6 +52,8 @@ def launch(case, nranks, expect_path, overlap=None, timeout=900):
                     "TORCHELASTIC_RUN_ID": "fs%d" % port, "PCL_FS_EXPECT": expect_path})
         if overlap is not None:
             env["PCL_HALO_OVERLAP"] = str(overlap)
+        if ahead is not None:
+            env["PCL_EXCHANGE_AHEAD"] = str(ahead)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_fullsize_worker.py"), case],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -129,9 +131,11 @@ def test_c4_blocks_decomposed_equals_serial_and_oracle_windows(case, coracle, tm
         assert np.array_equal(got, ref), (case, i0, j0, float(np.abs(got - ref).max()))
         assert not np.array_equal(ref, W.synth_euler(np.arange(i0, i0 + w) % nx, np.arange(j0, j0 + w) % ny))
     del q
-    log = launch(case, 4, path)
-    # the dimension-split cases run with the halo sent ahead (behind the previous y pass), the unsplit one cannot
-    assert ("exchange-ahead True" in log) == (case != "c4_unsplit"), log[-600:]
+    # Blocks that can all run the one-kernel step exchange in front of the step by default (and run its faster form);
+    # PCL_EXCHANGE_AHEAD=2 asks for that step's exchange-ahead order (rim tiles first, the new halo behind them):
+    # c4_periodic runs the default, c4_layout the exchange-ahead order; the unsplit step has none
+    log = launch(case, 4, path, ahead=2 if case == "c4_layout" else None)
+    assert ("exchange-ahead True" in log) == (case == "c4_layout"), log[-600:]
 
 
 def test_c4_layout_sequential_exchange(tmp_path):
@@ -142,17 +146,20 @@ def test_c4_layout_sequential_exchange(tmp_path):
     assert "exchange-ahead False" in log
 
 
-def test_c4_app_shockbubble_8192_decomposed_equals_serial(tmp_path):
+@pytest.mark.parametrize("ahead", [1, 2])
+def test_c4_app_shockbubble_8192_decomposed_equals_serial(ahead, tmp_path):
     """the shock-bubble app itself on the C4 grid: inflow / reflecting / outflow sides on the edge blocks only,
-    adaptive dt from the global Courant number (incl. the rejected first step), source term fused into the y pass"""
+    adaptive dt from the global Courant number (incl. the rejected first step), source term fused into the y pass;
+    in the default order (exchange, then the step in its faster form) and in the one-kernel step's exchange-ahead order"""
     q, out, path = serial_and_expect("c4_app", tmp_path)
     assert out["numsteps"] >= 3, out
     # the post-shock inflow state has entered on the left, the bubble is still where it was
     assert q[1, 0, :].min() > 0.0 and q[0].min() < 0.2
     del q
-    log = launch("c4_app", 4, path)
+    log = launch("c4_app", 4, path, ahead=ahead)
     assert "steps %d" % out["numsteps"] in log
-    assert "exchange-ahead True" in log        # incl. the rejected first step: back to the pre-step buffer's ghost frame
+    # (exchange-ahead incl. the rejected first step: back to the pre-step buffer's ghost frame)
+    assert ("exchange-ahead True" in log) == (ahead == 2), log[-600:]
 
 
 def sphere_window_replay(coracle, q0g, auxg, i0, j0, w, pad, dt, dx, dy):

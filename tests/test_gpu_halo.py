@@ -171,6 +171,71 @@ def test_overlapped_step_equals_periodic(mx, my, overlap, monkeypatch):
     assert not np.array_equal(res[0][0], q0)
 
 
+def test_sequential_decomposed_step_runs_both_forms(monkeypatch):
+    """The default of a decomposed run whose blocks can all run the one-kernel step: exchange in front of the step, then
+    the step in its FASTER form -- one kernel or x pass + y pass, re-measured by every rank for itself (trial steps 64
+    steps into a window of 256; pcl_bc_step -> pcl_step_hyperbolic).  80 steps on a block whose 8 neighbours are itself,
+    a rejected step and its retake among the trial steps: equal to the same sequence with local periodic fills, bit for
+    bit, Courant numbers included, and both forms did run (pcl_step_form_stats)."""
+    from pyclaw_amd import _lib as L
+    lib = L.lib()
+    monkeypatch.setenv("PCL_HALO_OVERLAP", "1")
+    mx, my, g = 300, 200, 2
+    rng = np.random.default_rng(31)
+    q0 = np.empty((5, mx, my), order="F")
+    q0[0] = 1 + 0.3 * rng.random((mx, my))
+    q0[1] = 0.3 * rng.standard_normal((mx, my))
+    q0[2] = 0.2 * rng.standard_normal((mx, my))
+    q0[3] = 2.5 + 0.5 * rng.random((mx, my))
+    q0[4] = rng.random((mx, my))
+    q0[:, 40:170, 30:150] = q0[:, 40:41, 30:31]           # an undisturbed patch: tiles whose wavefronts take the shortcut
+    dt = 2e-4 * 100 / mx
+    res = []
+    for with_comm in (False, True):
+        h = make_solver(L, mx, my)
+        try:
+            if with_comm:
+                uid = C.create_string_buffer(128)
+                L.check(lib.pcl_comm_unique_id(uid))
+                L.check(lib.pcl_comm_init(h, 1, 0, uid, L.i(np.zeros(8, dtype=np.int32))))
+                yes = C.c_int(0)
+                L.check(lib.pcl_halo_can_overlap(h, C.byref(yes)))
+                assert yes.value == 2                  # interior box of one-kernel tiles; no exchange-ahead is set
+                bc = np.full(4, -1, dtype=np.int32)
+            else:
+                bc = np.full(4, 2, dtype=np.int32)
+            poison = np.full((5, mx + 2 * g, my + 2 * g), np.nan, order="F")
+            L.check(lib.pcl_put_q(h, L.d(poison), 1))
+            L.check(lib.pcl_put_q(h, L.d(q0), 0))
+            consts = np.zeros(4 * 8)
+            cfls = []
+
+            def step(d):
+                cfl = C.c_double()
+                L.check(lib.pcl_bc_step(h, L.i(bc), L.d(consts), d, C.cast(C.byref(cfl), L.dp)))
+                cfls.append(cfl.value)
+            for k in range(80):
+                if k in (66, 70):                     # "rejected" among the trial steps of either form
+                    step(3 * dt)
+                    L.check(lib.pcl_undo_step(h))
+                    step(0.7 * dt)
+                else:
+                    step(dt)
+            out = np.zeros_like(q0)
+            L.check(lib.pcl_get_q(h, L.d(out), 0))
+            ms = np.zeros(3)
+            nl = np.zeros(3, dtype=np.int64)
+            s1, s0 = C.c_long(0), C.c_long(0)
+            L.check(lib.pcl_step_form_stats(h, L.d(ms), nl.ctypes.data_as(C.POINTER(C.c_long)), C.byref(s1), C.byref(s0)))
+            res.append((out, cfls, (s1.value, s0.value)))
+        finally:
+            lib.pcl_destroy(h)
+    assert res[0][1] == res[1][1] and 0 < res[0][1][0] < 1
+    assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
+    for (_, _, (one, two)) in res:                     # 82 steps incl. the two rejected ones, both forms among them
+        assert one + two == 82 and one >= 4 and two >= 4, res[0][2:] + res[1][2:]
+
+
 @pytest.mark.parametrize("mx,my,order", [(1000, 37, 0), (723, 9, 0), (4096, 2048, 0), (4096, 2048, 1), (1024, 300, 1)])
 def test_exchange_ahead_equals_periodic_with_retake(mx, my, order, monkeypatch):
     """pcl_halo_exchange_ahead: the halo of the new state is exchanged behind the y pass that produced it and the next
