@@ -1381,7 +1381,9 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
                 s->vconst[k][m] = (s->vbc[k] == PCL_BC_CUSTOM) ? cstate[k * PCL_MAX_RP_PARAMS + m] : 0.0;
         }
         s->vbc_on = 1;
+        s->form_seq_tune = s->halo.active ? 1 : 0;      // a decomposed block behind its exchange: the faster form, too
         const int rc = pcl_step_hyperbolic(s, dt, cfl);
+        s->form_seq_tune = 0;
         s->vbc_on = 0;
         return rc;
     }
