@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""tools/bench_summary.py <bench JSON file> -- one line with the rates of a default `bench.py` line (headline, step forms,
+dense / developed state, app figure, app run per quarter, fast mode), for same-box comparisons of library builds."""
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 ar=d.get('app_run',{})

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round-3 profile artefacts (run through gpurun; copy gpurun_out/prof_<tag>/summary/* into profiles/ afterwards).
-#   1. rocprofv3 --kernel-trace --stats of one bench command per kernel family, the bench JSON of the SAME run next to it;
-#   2. in SEPARATE passes --pmc FETCH_SIZE / --pmc WRITE_SIZE (MI355X_MICROARCH.md: KB units, FETCH_SIZE x2 on gfx950) of
-#      the same commands -> <tag>_pmc_hbm.json via tools/pmc_summary.py (bench.py reads roofline.traffic from it);
+#   1. in SEPARATE passes --pmc FETCH_SIZE / --pmc WRITE_SIZE (MI355X_MICROARCH.md: KB units, FETCH_SIZE x2 on gfx950) of
+#      one bench command per kernel family -> <tag>_pmc_hbm.json via tools/pmc_summary.py (bench.py reads
+#      roofline.traffic from it; written into the box's profiles/ first, so the lines of step 2 carry THIS build's bytes);
+#   2. rocprofv3 --kernel-trace --stats of the same commands, the bench JSON of the SAME run next to it;
 #   3. SQ issue counters of the dense state (one-kernel step; PCL_TUNE_FUSED_STEP=0: the two passes) and of the SharpClaw
 #      right-hand side, and SQ_LDS_BANK_CONFLICT of the y pass with the swizzled tile (the build)
 #      and with the padded round-1 tile (build/libs/libpyclaw_amd_ypad.so, -DPCL_YTILE_PAD=1).
