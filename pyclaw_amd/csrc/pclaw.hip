@@ -84,6 +84,7 @@ struct pcl_solver {
     hipStream_t hstream = nullptr;
     hipEvent_t ev_h0 = nullptr, ev_h1 = nullptr;
     int overlap = 1;
+    bool overlap_dflt = true;       // PCL_HALO_OVERLAP not set: the library picks per kernel family (twopass_overlap_ok)
     // Exchange-ahead (pcl_halo_exchange_ahead): the halo exchange of the NEW state is enqueued on the halo stream
     // right behind the y pass that produced it, so it runs through the hand-over of the Courant number, the host's
     // accept / retake decision and the first tiles of the next x pass instead of in front of that pass' rim tiles.
@@ -457,6 +458,18 @@ bool fused_step_ok(const pcl_solver *s) {
     const int rp = s->cfg.rp;
     return on && s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.mbc == 2 && s->cfg.method[5] <= 0 && s->cfg.meqn <= 5 &&
            (rp == PCL_RP_EULER5_2D || rp == PCL_RP_ACOUSTICS_2D || rp == PCL_RP_ADVECTION_2D || rp == PCL_RP_SHALLOW_2D);
+}
+// The two-pass dim-split step of a decomposed block with its interior x tiles BESIDE the exchange.  For the solver
+// family of the one-kernel step (aux-free, no capacity function: an x pass register-allocated for four workgroups per
+// CU) the interior launch starves the halo stream's pack / Send-Recv kernels (44 / 77 us instead of 6 / 34) and the step
+// is slower than with the exchange in front (4096 x 2048 Euler block: 0.489 against 0.320 ms), so those blocks -- too
+// thin for one-kernel tiles, mbc > 2, PCL_TUNE_FUSED_STEP=0 -- take the exchange in front unless PCL_HALO_OVERLAP=1 is
+// set explicitly (tests, A/B).  Solvers with aux arrays or a capacity function keep the overlap.
+bool twopass_overlap_ok(const pcl_solver *s) {
+    const int rp = s->cfg.rp;
+    const bool onek_family = s->cfg.ndim == 2 && s->cfg.method[2] < 0 && s->cfg.method[5] <= 0 &&
+                             (rp == PCL_RP_EULER5_2D || rp == PCL_RP_ACOUSTICS_2D || rp == PCL_RP_ADVECTION_2D || rp == PCL_RP_SHALLOW_2D);
+    return !(onek_family && s->overlap_dflt);
 }
 int do_step2ds(pcl_solver *s, const double *qin, double *qout, double dt, int sub = 0, const int *box = nullptr,
                hipStream_t on = nullptr) {
@@ -1210,7 +1223,8 @@ int pcl_bc_step(pcl_solver *s, const int *bc, const double *cstate, double dt, d
         if (onek && pcl::exact::step2ds_interior_box(make_args(s, s->q, s->t2, 1, dt), box, ntiles)) overlapped = true;
         else {
             onek = false;
-            overlapped = pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, dt), box, ntiles);
+            overlapped = (twopass_overlap_ok(s) || s->exchange_ahead == 1) &&
+                         pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, dt), box, ntiles);
         }
     }
     if (!overlapped) s->ghosts_drop_all();       // exchange-ahead lives in the overlapped dimension-split step only
@@ -2041,6 +2055,7 @@ int pcl_comm_init(pcl_solver *s, int nranks, int rank, const char uid[128], cons
     }
     const char *e = getenv("PCL_HALO_OVERLAP");
     s->overlap = e ? atoi(e) : 1;
+    s->overlap_dflt = e == nullptr;
     return PCL_OK;
 }
 
@@ -2064,6 +2079,7 @@ int pcl_comm_init_host(pcl_solver *s, int nranks, int rank, const int neighbors[
     }
     const char *e = getenv("PCL_HALO_OVERLAP");
     s->overlap = e ? atoi(e) : 1;
+    s->overlap_dflt = e == nullptr;
     return PCL_OK;
 }
 
@@ -2075,7 +2091,7 @@ int pcl_halo_can_overlap(pcl_solver *s, int *yes) {
     // 2: this block can also run the one-kernel step with interior / rim tile subsets; 1: the two-pass step only
     *yes = !base ? 0
            : (fused_step_ok(s) && pcl::exact::step2ds_interior_box(make_args(s, s->q, s->t2, 1, 1.0), box, ntiles)) ? 2
-           : pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, 1.0), box, ntiles) ? 1 : 0;
+           : (twopass_overlap_ok(s) && pcl::exact::x_interior_box(make_args(s, s->q, s->t1, 1, 1.0), box, ntiles)) ? 1 : 0;
     return PCL_OK;
 }
 

@@ -69,3 +69,11 @@ def test_decomposed_device_run_equals_serial(case, nranks):
 def test_decomposed_device_run_sequential_exchange(case):
     """PCL_HALO_OVERLAP=0: the exchange in front of the step on one stream"""
     launch(case, 4, overlap=0)
+
+
+@pytest.mark.parametrize("case,nranks", [("shockbubble_ds", 4), ("acoustics_ds", 4), ("acoustics_ds_mbc3", 4)])
+def test_decomposed_device_run_explicit_overlap(case, nranks):
+    """PCL_HALO_OVERLAP=1 set explicitly: the two-pass dimension-split step with its interior x tiles beside the exchange
+    (and exchange-ahead where the blocks agree on it) -- by default blocks of the aux-free solvers that cannot run the
+    one-kernel step take the exchange in front of the step (pclaw.hip: twopass_overlap_ok)"""
+    launch(case, nranks, overlap=1)
