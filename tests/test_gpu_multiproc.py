@@ -71,9 +71,12 @@ def test_decomposed_device_run_sequential_exchange(case):
     launch(case, 4, overlap=0)
 
 
-@pytest.mark.parametrize("case,nranks", [("shockbubble_ds", 4), ("acoustics_ds", 4), ("acoustics_ds_mbc3", 4)])
+@pytest.mark.parametrize("case,nranks", [("shockbubble_ds", 4), ("acoustics_ds", 4), ("acoustics_ds_mbc3", 4),
+                                         ("shockbubble_unsplit", 4), ("acoustics_unsplit", 4), ("sphere_classic", 4),
+                                         ("rotating_classic", 4)])
 def test_decomposed_device_run_explicit_overlap(case, nranks):
     """PCL_HALO_OVERLAP=1 set explicitly: the two-pass dimension-split step with its interior x tiles beside the exchange
     (and exchange-ahead where the blocks agree on it) -- by default blocks of the aux-free solvers that cannot run the
-    one-kernel step take the exchange in front of the step (pclaw.hip: twopass_overlap_ok)"""
+    one-kernel step take the exchange in front of the step (pclaw.hip: twopass_overlap_ok) -- and the unsplit step with
+    its interior x-phase tiles beside the exchange, which also runs only on request now (pcl_bc_step)"""
     launch(case, nranks, overlap=1)

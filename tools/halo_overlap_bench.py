@@ -25,6 +25,8 @@ def run(mx, my, steps, comm, overlap, ahead=False, state="uniform"):
     cfg.mbc = 2
     cfg.meqn, cfg.mwaves, cfg.rp = 5, 5, 11
     cfg.method[1], cfg.method[2] = 2, -1
+    if os.environ.get("PCL_HALO_BENCH_UNSPLIT"):         # the unsplit step (order_trans = 2) instead of the dim-split one
+        cfg.method[2] = 2
     for k, v in enumerate([4, 4, 4, 4, 2]):
         cfg.mthlim[k] = v
     cfg.rp_params[0], cfg.rp_params[1] = 1.4, 0.4
